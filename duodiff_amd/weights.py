@@ -1,0 +1,88 @@
+"""Parameter inventory (= checkpoint schema) and seeded synthetic weights.
+
+The names and shapes follow the state_dict of reference ``UViT.__init__``
+(models/uvit.py:228-336), so that reference checkpoints
+load by name.  No trained checkpoints exist offline, so benchmarks and parity
+fixtures use ``synthetic_state_dict``: every tensor -- including biases and
+LayerNorm gamma/beta, which the reference's init zeroes -- is drawn from a seeded
+torch-CPU generator (recipe in SURVEY section 8d).
+"""
+from collections import OrderedDict
+
+import torch
+
+from .config import ModelParams
+
+
+def _block(prefix, D, hidden, skip):
+    s = OrderedDict()
+    s[prefix + "norm1.weight"] = (D,)
+    s[prefix + "norm1.bias"] = (D,)
+    s[prefix + "attn.qkv.weight"] = (3 * D, D)
+    s[prefix + "attn.proj.weight"] = (D, D)
+    s[prefix + "attn.proj.bias"] = (D,)
+    s[prefix + "norm2.weight"] = (D,)
+    s[prefix + "norm2.bias"] = (D,)
+    s[prefix + "mlp.fc1.weight"] = (hidden, D)
+    s[prefix + "mlp.fc1.bias"] = (hidden,)
+    s[prefix + "mlp.fc2.weight"] = (D, hidden)
+    s[prefix + "mlp.fc2.bias"] = (D,)
+    if skip:
+        s[prefix + "skip_linear.weight"] = (D, 2 * D)
+        s[prefix + "skip_linear.bias"] = (D,)
+    return s
+
+
+def param_shapes(mp: ModelParams) -> "OrderedDict[str, tuple]":
+    """name -> shape for every tensor in the reference state_dict."""
+    D, P, C = mp.embed_dim, mp.patch_size, mp.in_chans
+    hidden = int(D * mp.mlp_ratio)
+    s = OrderedDict()
+    s["pos_embed"] = (1, mp.seq_len, D)
+    s["patch_embed.proj.weight"] = (D, C, P, P)
+    s["patch_embed.proj.bias"] = (D,)
+    if mp.num_classes > 0:
+        s["label_emb.weight"] = (mp.num_classes, D)
+    for i in range(mp.depth // 2):
+        s.update(_block(f"in_blocks.{i}.", D, hidden, False))
+    s.update(_block("mid_block.", D, hidden, False))
+    for i in range(mp.depth // 2):
+        s.update(_block(f"out_blocks.{i}.", D, hidden, True))
+    s["norm.weight"] = (D,)
+    s["norm.bias"] = (D,)
+    s["decoder_pred.weight"] = (mp.patch_dim, D)
+    s["decoder_pred.bias"] = (mp.patch_dim,)
+    s["final_layer.weight"] = (C, C, 3, 3)
+    s["final_layer.bias"] = (C,)
+    return s
+
+
+def num_params(mp: ModelParams) -> int:
+    n = 0
+    for shp in param_shapes(mp).values():
+        k = 1
+        for d in shp:
+            k *= d
+        n += k
+    return n
+
+
+def synthetic_state_dict(mp: ModelParams, seed: int = 1234, weight_std: float = 0.02) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded fp32 state_dict: W ~ N(0, std^2), b ~ N(0, 0.02^2), LN gamma ~ 1+N(0, 0.1^2).
+
+    ``final_layer`` (3x3 conv) uses std 0.2 so the conv is not a near-null map.
+    Draw order is the ``param_shapes`` order; the stream is torch-CPU mt19937.
+    """
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    sd = OrderedDict()
+    for name, shp in param_shapes(mp).items():
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(shp, generator=g)
+        elif name.startswith("final_layer"):
+            t = 0.2 * torch.randn(shp, generator=g)
+        else:
+            t = weight_std * torch.randn(shp, generator=g)
+        sd[name] = t.to(torch.float32).contiguous()
+    return sd

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Run only in the build container (needs /root/reference, which never ships):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The fixtures are data only -- inputs and the reference's outputs.  Weights are not
+stored: they are regenerated from ``duodiff_amd.weights.synthetic_state_dict``
+(seeded), which is also how the tests rebuild them on the GPU box.
+
+Fixtures:
+  schedule.npz        F2  five fp32[1000] tables from sampler.py:40-44 and ddpm_core.py:64-70
+  step.npz            F3  (x, eps, z, t) -> x' from predict_noise_postprocessing, six t values
+  uvit_tiny_*.npz     F1  per-op taps of a tiny U-ViT (uncond/cond x normalise on/off)
+  rollout_tiny.npz    F4  get_samples with late_model, t_switch=300, seed 0, B=2
+  uvit_full_*.npz     F5  full-size forwards (B=2) of the shipped YAMLs: slice + stats + checksum
+  rng.npz             F6  first values of the torch CPU randn stream after seed_everything(0)
+  scheduler_tiny.npz      NoiseScheduler.sample with the tiny model (ddpm_core loop)
+"""
+import contextlib
+import io
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path(os.environ.get("DUODIFF_REFERENCE", "/root/reference"))
+OUT = REPO / "tests" / "golden"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REPO))
+sys.path.insert(1, str(REF))
+
+from duodiff_amd.config import ModelParams, load_config  # noqa: E402
+from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import ddpm_core as ref_ddpm  # noqa: E402
+    import sampler as ref_sampler  # noqa: E402
+    from models.uvit import UViT as RefUViT  # noqa: E402
+    from utils.train_utils import seed_everything as ref_seed_everything  # noqa: E402
+
+TINY = dict(img_size=8, patch_size=2, in_chans=3, embed_dim=64, depth=3, num_heads=1, mlp_ratio=4,
+            qkv_bias=False, mlp_time_embed=False, num_classes=-1, normalize_timesteps=True)
+
+
+def build_ref(cfg, seed):
+    mp = ModelParams.from_dict(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = RefUViT(**mp.as_dict())
+    m.load_state_dict(synthetic_state_dict(mp, seed), strict=True)
+    return m.eval(), mp
+
+
+def gen_schedule():
+    s = ref_ddpm.NoiseScheduler()
+    np.savez(OUT / "schedule.npz",
+             sampler_betas=ref_sampler.betas.numpy(), sampler_alphas=ref_sampler.alphas.numpy(),
+             sampler_alphas_bar=ref_sampler.alphas_bar.numpy(),
+             sampler_alphas_bar_previous=ref_sampler.alphas_bar_previous.numpy(),
+             sampler_betas_tilde=ref_sampler.betas_tilde.numpy(),
+             sched_betas=s.betas.numpy(), sched_alphas=s.alphas.numpy(),
+             sched_alphas_bar=s.alphas_bar.numpy(), sched_alpha_bar_prev=s.alpha_bar_prev.numpy(),
+             sched_betas_tilde=s.betas_tilde.numpy())
+
+
+def gen_step():
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    eps = torch.randn(2, 3, 8, 8, generator=g)
+    out = dict(x=x.numpy(), eps=eps.numpy())
+    ts = [999, 700, 699, 500, 1, 0]
+    for t in ts:
+        torch.manual_seed(1000 + t)
+        z = torch.randn(x.shape)          # what randn_like(x) will draw next
+        torch.manual_seed(1000 + t)
+        xn = ref_sampler.predict_noise_postprocessing(eps, x, t)
+        out[f"z_{t}"] = z.numpy()
+        out[f"xnext_{t}"] = xn.numpy()
+    out["ts"] = np.array(ts)
+    np.savez(OUT / "step.npz", **out)
+
+
+def gen_tiny():
+    variants = {
+        "uncond_norm": dict(TINY),
+        "uncond_raw": dict(TINY, normalize_timesteps=False),
+        "cond_raw": dict(TINY, num_classes=10, normalize_timesteps=False),
+        "cond_norm_h2": dict(TINY, num_classes=10, embed_dim=128, num_heads=2, depth=5),
+    }
+    for vi, (name, cfg) in enumerate(variants.items()):
+        m, mp = build_ref(cfg, seed=100 + vi)
+        g = torch.Generator().manual_seed(200 + vi)
+        B = 3
+        x = torch.randn(B, mp.in_chans, mp.img_size, mp.img_size, generator=g)
+        t = torch.tensor([999.0, 500.0, 3.0])
+        y = torch.tensor([1, 9, 4]) if mp.num_classes > 0 else None
+        taps = {}
+        hooks = []
+
+        def tap(key):
+            def fn(_mod, _inp, out):
+                taps[key] = out.detach().numpy().copy()
+            return fn
+
+        for i, blk in enumerate(m.in_blocks):
+            hooks.append(blk.register_forward_hook(tap(f"in_blocks.{i}")))
+        hooks.append(m.mid_block.register_forward_hook(tap("mid_block")))
+        for i, blk in enumerate(m.out_blocks):
+            hooks.append(blk.register_forward_hook(tap(f"out_blocks.{i}")))
+        hooks.append(m.in_blocks[0].register_forward_pre_hook(
+            lambda _m, inp: taps.__setitem__("tokens", inp[0].detach().numpy().copy())))
+        hooks.append(m.decoder_pred.register_forward_hook(tap("decoder_pred_all")))
+        hooks.append(m.in_blocks[0].attn.register_forward_hook(tap("in_blocks.0.attn")))
+        hooks.append(m.in_blocks[0].mlp.register_forward_hook(tap("in_blocks.0.mlp")))
+        with torch.no_grad():
+            eps = m(x, t, y)
+        for h in hooks:
+            h.remove()
+        out = {"tap_" + k: v for k, v in taps.items()}
+        out["tap_decoder_pred"] = taps["decoder_pred_all"][:, mp.extras:, :]
+        del out["tap_decoder_pred_all"]
+        out.update(x=x.numpy(), t=t.numpy(), eps=eps.numpy(), seed=np.array(100 + vi))
+        if y is not None:
+            out["y"] = y.numpy()
+        out["cfg_keys"] = np.array(list(cfg.keys()))
+        out["cfg_vals"] = np.array([float(v) for v in cfg.values()])
+        np.savez(OUT / f"uvit_tiny_{name}.npz", **out)
+
+
+def gen_rollout():
+    shallow_cfg = dict(TINY, depth=1)
+    full_cfg = dict(TINY, depth=3)
+    m_s, mp = build_ref(shallow_cfg, seed=300)
+    m_f, _ = build_ref(full_cfg, seed=301)
+    calls = {"s": 0, "f": 0}
+    want = {999, 998, 700, 699, 1, 0}
+    rec = {}
+    state = {"t": 999}
+
+    class Count(torch.nn.Module):
+        def __init__(self, inner, key):
+            super().__init__()
+            self.inner, self.key = inner, key
+
+        def forward(self, x, t, y=None):
+            calls[self.key] += 1
+            return self.inner(x, t, y)
+
+    orig_post = ref_sampler.predict_noise_postprocessing
+
+    def post(model_output, x, t):
+        xn = orig_post(model_output, x, t)
+        if t in want:
+            rec[t] = xn.numpy().copy()
+        return xn
+
+    with contextlib.redirect_stderr(io.StringIO()):
+        samples, _ = ref_sampler.get_samples(
+            model=Count(m_s, "s"), batch_size=2, postprocessing=post, seed=0,
+            num_channels=3, sample_height=8, sample_width=8, use_ddim=False, ddim_steps=50,
+            ddim_eta=0.0, timesteps_save=[], y=None, autoencoder=None,
+            late_model=Count(m_f, "f"), t_switch=300)
+    del state
+    out = {f"x_after_{t}": v for t, v in rec.items()}
+    out.update(samples=samples, calls_first=np.array(calls["s"]), calls_late=np.array(calls["f"]),
+               seed_first=np.array(300), seed_late=np.array(301))
+    np.savez(OUT / "rollout_tiny.npz", **out)
+
+
+def gen_scheduler():
+    m, mp = build_ref(dict(TINY, depth=1), seed=400)
+    sch = ref_ddpm.NoiseScheduler(beta_steps=50)
+    with contextlib.redirect_stderr(io.StringIO()):
+        x0, log = sch.sample(m, num_steps=50, data_shape=(3, 8, 8), num_samples=2, seed=5, model_type="uvit")
+    np.savez(OUT / "scheduler_tiny.npz", x0=x0.numpy(), x_after_first=log["samples_over_time"][0].numpy(),
+             x_mid=log["samples_over_time"][25].numpy(), seed=np.array(400))
+
+
+def gen_full():
+    names = ["uvit_cifar10", "uvit_cifar10_3", "uvit_celeba", "uvit_celeba_3",
+             "uvit_imagenet64", "uvit_imagenet64_3", "uvit_imagenet256", "uvit_imagenet256_3"]
+    for mi, name in enumerate(names):
+        cfg = load_config(REPO / "configs" / f"{name}.yaml")
+        m, mp = build_ref(cfg, seed=1234 + mi)
+        g = torch.Generator().manual_seed(9000 + mi)
+        B = 2
+        x = torch.randn(B, mp.in_chans, mp.img_size, mp.img_size, generator=g)
+        tval = 417.0
+        t = tval * torch.ones(B)
+        y = torch.tensor([7, 993]) if mp.num_classes > 0 else None
+        with torch.no_grad():
+            eps = m(x, t, y).numpy()
+        np.savez(OUT / f"uvit_full_{name}.npz", x=x.numpy(), t=np.array(tval, np.float32),
+                 y=(y.numpy() if y is not None else np.zeros(0, np.int64)),
+                 eps_slice=eps[:, :, :16, :16].copy(),
+                 stats=np.array([eps.mean(dtype=np.float64), eps.std(dtype=np.float64), eps.min(), eps.max()]),
+                 checksum=np.array(eps.astype(np.float64).sum()),
+                 abs_checksum=np.array(np.abs(eps.astype(np.float64)).sum()),
+                 seed=np.array(1234 + mi))
+        print(name, "eps std", float(eps.std()), flush=True)
+
+
+def gen_rng():
+    ref_seed_everything(0)
+    a = torch.randn(64)
+    ref_seed_everything(0)
+    b = torch.randn(2, 3, 8, 8)
+    c = torch.randn(2, 3, 8, 8)
+    ref_seed_everything(0)
+    y = torch.randint(1, 1001, (16,))
+    np.savez(OUT / "rng.npz", first64=a.numpy(), x_T=b.numpy(), z_first=c.numpy(), y_first16=y.numpy())
+
+
+if __name__ == "__main__":
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "full"]
+    for w in which:
+        print("generating", w, flush=True)
+        globals()["gen_" + w]()
+    print("done")
