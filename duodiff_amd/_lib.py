@@ -1,0 +1,78 @@
+"""ctypes binding of libduodiff.so (include/duodiff.h).  No CPU fallback: a missing
+library is an ImportError-class failure raised at first use, loudly."""
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libduodiff.so"
+
+DD_OK = 0
+DD_ERR_INVALID, DD_ERR_NOT_FOUND, DD_ERR_STATE, DD_ERR_HIP, DD_ERR_NOMEM, DD_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+DD_PREC_BF16, DD_PREC_FP32 = 0, 1
+DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
+DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
+ABI_VERSION = 1
+
+
+class dd_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads", "mlp_ratio",
+        "num_classes", "normalize_timesteps", "max_batch")]
+
+
+class dd_sample_args(C.Structure):
+    _fields_ = [("first", C.c_void_p), ("late", C.c_void_p), ("t_switch", C.c_int32),
+                ("t_start", C.c_int32), ("t_end", C.c_int32), ("variance", C.c_int32),
+                ("noise_mode", C.c_int32), ("use_graph", C.c_int32), ("seed", C.c_uint64),
+                ("y_dev", C.c_void_p), ("x_dev", C.c_void_p), ("B", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/duodiff.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dd_abi_version": (C.c_int, []),
+    "dd_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "dd_ctx_destroy": (None, [C.c_void_p]),
+    "dd_last_error": (C.c_char_p, [C.c_void_p]),
+    "dd_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dd_schedule_table": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "dd_model_create": (C.c_int, [C.c_void_p, C.POINTER(dd_config), C.POINTER(C.c_void_p)]),
+    "dd_model_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "dd_model_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "dd_model_num_params": (C.c_int64, [C.c_void_p]),
+    "dd_model_destroy": (None, [C.c_void_p]),
+    "dd_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dd_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dd_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dd_sample": (C.c_int, [C.c_void_p, C.POINTER(dd_sample_args), C.c_void_p]),
+    "dd_bench_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "dd_last_sample_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    """libduodiff.so is missing or unusable.  There is no CPU path to fall back to."""
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises EngineUnavailable if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EngineUnavailable(
+            f"{LIB_PATH} not found: build it with `python -m duodiff_amd.build` "
+            "(hipcc --offload-arch=gfx950).  duodiff_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise EngineUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dd_abi_version() != ABI_VERSION:
+        raise EngineUnavailable("libduodiff.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib

@@ -1,0 +1,248 @@
+// Single-pass attention for the U-ViT token sequence (L <= 288, head_dim = 64) on gfx950.
+//
+// reference models/uvit.py:155-164: q,k,v = split(qkv) ; softmax(q k^T / sqrt(64)) v per (b, h),
+// fp32 softmax, no mask, heads merged back as "B H L D -> B L (H D)".
+//
+// One workgroup = one (image, head).  K ([L,64], row-major, padded rows) and V^T ([64,L]) of
+// the head live in LDS for the whole kernel; every wave takes 32-query chunks:
+//   S^T[key, q] = K . Q^T        (MFMA A = K rows from LDS, B = Q fragment straight from HBM)
+//   softmax over keys            = over accumulator registers (+ one 32-lane exchange): the key
+//                                  index sits in the 16 registers x 2 lane-halves of each 32x32
+//                                  tile and the query on the lane, so no LDS round trip
+//   O^T[d, q]  = V^T . P^T       (A = V^T from LDS, B = the S^T accumulators re-used in place as
+//                                  the next MFMA's operand: their k order is the accumulator row
+//                                  order  row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+// The L x L score matrix is never written anywhere (reference: 270 MB per layer at B=128).
+// Works in bf16 (v_mfma_f32_32x32x16_bf16) and in the fp32 parity mode (v_mfma_f32_32x32x2_f32).
+#include "dd_internal.h"
+
+namespace dd {
+namespace {
+
+constexpr int kMaxKeyTiles = 9;          // 9 x 32 = 288 >= 258
+constexpr int kLP = kMaxKeyTiles * 32;   // padded key count held in LDS
+constexpr int kHD = 64;
+
+template <typename T> struct AttnLayout;
+template <> struct AttnLayout<bf16_t> {
+    static constexpr int kRowK = 128 + 16;        // K row: 64 bf16 + 16 B pad  (36 dwords: b128 reads conflict-free)
+    static constexpr int kRowV = kLP * 2 + 8;     // V^T row: 288 bf16 + 8 B pad (146 dwords = 2 mod 64: b64 reads conflict-free)
+};
+template <> struct AttnLayout<float> {
+    static constexpr int kRowK = 256 + 16;        // 68 dwords = 4 mod 64
+    static constexpr int kRowV = kLP * 4 + 16;    // 292 dwords = 4 mod 64
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, int H, int D) {
+    using Lay = AttnLayout<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                   // [kLP][kRowK]
+    char* Vt = smem + kLP * Lay::kRowK;                // [64][kRowV]
+
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, r32 = lane & 31;
+    const long long ld = 3LL * D;
+    const T* qbase = qkv + (long long)b * L * ld + hh * kHD;
+    const T* kbase = qbase + D;
+    const T* vbase = qbase + 2 * D;
+    const int nkt = (L + 31) / 32;                     // key tiles actually used
+    constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte chunk
+    constexpr int CPR = kHD / EPC;                     // chunks per row (8 bf16 / 16 fp32)
+
+    // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
+    for (int idx = tid; idx < nkt * 32 * CPR; idx += 256) {
+        const int key = idx / CPR, ch = idx % CPR;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (key < L) {
+            kv = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
+            vv = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
+        }
+        *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = kv;
+        T tmp[EPC];
+        *reinterpret_cast<f32x4*>(tmp) = vv;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            *reinterpret_cast<T*>(Vt + (ch * EPC + e) * Lay::kRowV + key * (int)sizeof(T)) = tmp[e];
+    }
+    __syncthreads();
+
+    const int nqc = (L + 31) / 32;
+    for (int qc = wave; qc < nqc; qc += 4) {
+        const int q = qc * 32 + r32;
+        const int qs = q < L ? q : L - 1;              // clamp: rows >= L are computed and dropped
+        const T* qrow = qbase + (long long)qs * ld;
+
+        // ---- S^T = K . Q^T, nkt tiles of 32 keys x 32 queries
+        f32x16 s[kMaxKeyTiles];
+#pragma unroll
+        for (int t = 0; t < kMaxKeyTiles; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 qf[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                qf[st] = *reinterpret_cast<const bf16x8*>(qrow + 16 * st + 8 * half);
+#pragma unroll
+            for (int t = 0; t < kMaxKeyTiles; ++t) {
+                if (t < nkt) {
+                    const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
+                        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
+            f32x4 qf[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                qf[g] = *reinterpret_cast<const f32x4*>(qrow + 32 * half + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kMaxKeyTiles; ++t) {
+                if (t < nkt) {
+                    const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + g * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], s[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- softmax over keys (registers x tiles in-lane, then the other lane-half)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < kMaxKeyTiles; ++t) {
+            if (t < nkt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const float v = key < L ? s[t][e] * 0.125f : -INFINITY;   // 1/sqrt(64), exact
+                    s[t][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < kMaxKeyTiles; ++t) {
+            if (t < nkt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = sizeof(T) == 2 ? __expf(s[t][e] - mx) : expf(s[t][e] - mx);
+                    s[t][e] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T . P^T : two 32(d) x 32(q) tiles
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int t = 0; t < kMaxKeyTiles; ++t) {
+                if (t < nkt) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
+                        // t*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
+                        bf16x8 pf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[t][8 * st + j]);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 16 * st + 4 * half) * 2;
+                            typedef __attribute__((ext_vector_type(4))) short s4;
+                            const s4 lo = *reinterpret_cast<const s4*>(vr);        // keys +0..3
+                            const s4 hi = *reinterpret_cast<const s4*>(vr + 16);   // keys +8..11
+                            bf16x8 vf;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kMaxKeyTiles; ++t) {
+                if (t < nkt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // registers 4g..4g+3 are keys t*32 + 8g + 4*half + (0..3): contiguous in V^T
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 8 * g + 4 * half) * 4;
+                            const f32x4 vf = *reinterpret_cast<const f32x4*>(vr);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[t][4 * g + e], o[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- store: lane = query, registers = d ; 4 consecutive d per register quad
+        if (q < L) {
+            T* orow = out + ((long long)b * L + q) * D + hh * kHD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * half;
+                    T v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = Elem<T>::from_f32(o[dt][4 * g + e] * inv);
+                    if constexpr (sizeof(T) == 2) {
+                        *reinterpret_cast<uint2*>(orow + d) = *reinterpret_cast<const uint2*>(v4);
+                    } else {
+                        *reinterpret_cast<f32x4*>(orow + d) = *reinterpret_cast<const f32x4*>(v4);
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s) {
+    if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
+    using Lay = AttnLayout<T>;
+    const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)kHD * Lay::kRowV;
+    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
+    return hipGetLastError();
+}
+
+hipError_t init_attention_kernels() {
+    hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV);
+    return e;
+}
+
+template hipError_t launch_attention<bf16_t>(const bf16_t*, bf16_t*, int, int, int, int, hipStream_t);
+template hipError_t launch_attention<float>(const float*, float*, int, int, int, int, hipStream_t);
+
+}  // namespace dd

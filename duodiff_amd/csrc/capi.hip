@@ -1,0 +1,659 @@
+// extern "C" surface of libduodiff.so (include/duodiff.h): context, model packing, the U-ViT
+// forward as a sequence of HIP kernels, the fused sampling step and the hipGraph-replayed loop.
+//
+// Host-side restatement of: UViT.__init__ / forward wiring (reference models/uvit.py:228-383),
+// get_samples DDPM branch and backbone switch (sampler.py:128-139), schedule constants
+// (sampler.py:40-44, ddpm_core.py:64-70).
+#include "../../include/duodiff.h"
+#include "dd_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace dd;
+
+namespace dd {
+hipError_t init_gemm_kernels();
+hipError_t init_attention_kernels();
+hipError_t init_rowops_kernels();
+}  // namespace dd
+
+// ------------------------------------------------------------------------------------------
+struct dd_ctx {
+    int device = 0;
+    std::string err;
+    StepState* st = nullptr;     // device
+    StepCoef* coef = nullptr;    // device [1000]
+    StepCoef coef_host[1000];
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    float timing[3] = {0, 0, 0};
+};
+
+namespace {
+
+struct HostParam {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    bool set = false;
+};
+
+struct BlockW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *proj_b, *fc1_b, *fc2_b, *skip_b;
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w, *skip_w;
+};
+
+struct GraphKey {
+    const void* x; const void* y; int B, noise, variance;
+    bool operator==(const GraphKey& o) const {
+        return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance;
+    }
+};
+
+}  // namespace
+
+struct dd_model {
+    dd_ctx* ctx = nullptr;
+    dd_config cfg{};
+    int D = 0, L = 0, N = 0, extras = 0, pd = 0, pdp = 0, H = 0, hidden = 0, half_depth = 0, Mp_max = 0;
+    std::map<std::string, HostParam> params;
+    bool finalized = false;
+    int prec = DD_PREC_BF16;
+    size_t esize = 2;
+    char* warena = nullptr;    // weights
+    char* wsarena = nullptr;   // activations
+    std::vector<BlockW> blocks;  // in.., mid, out..
+    const float *emb_wt = nullptr, *emb_b = nullptr, *pos = nullptr, *label = nullptr;
+    const float *norm_g = nullptr, *norm_b = nullptr, *wdt = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
+    float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
+    std::vector<void*> skips;
+    float* dec = nullptr;
+    hipGraphExec_t graph = nullptr;
+    GraphKey gkey{};
+};
+
+namespace {
+
+int fail(dd_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int fail_hip(dd_ctx* c, hipError_t e, const char* what) {
+    return fail(c, DD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define DD_HIP(c, expr)                                          \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return fail_hip((c), _e, #expr);   \
+    } while (0)
+
+// ---- schedule: bit-for-bit the fp32 tables of sampler.py:40-44 (see oracle/schedule_oracle.py)
+struct Schedule {
+    float betas[1000], alphas[1000], abar[1000], abar_prev[1000], bt_sampler[1000], bt_sched[1000];
+    float c1[1000], c2[1000], sigma[1000], sigma_beta[1000];
+    Schedule() {
+        const float start = 1e-4f, end = 0.02f;
+        const float stepf = (end - start) / 999.0f;
+        const double step = (double)stepf;
+        for (int i = 0; i < 1000; ++i) {
+            // torch.linspace: one rounding per element, forward from start / backward from end
+            betas[i] = i < 500 ? (float)((double)start + step * i) : (float)((double)end - step * (999 - i));
+            alphas[i] = 1.0f - betas[i];
+        }
+        double run = 1.0;  // torch.cumprod (CPU) accumulates in double, rounds each output
+        for (int i = 0; i < 1000; ++i) {
+            run *= (double)alphas[i];
+            abar[i] = (float)run;
+        }
+        for (int i = 0; i < 1000; ++i) abar_prev[i] = i ? abar[i - 1] : 1.0f;
+        for (int i = 0; i < 1000; ++i) {
+            volatile float num = betas[i] * (1.0f - abar_prev[i]);
+            bt_sampler[i] = num / (1.0f - abar[i]);
+            volatile float ratio = (1.0f - abar_prev[i]) / (1.0f - abar[i]);
+            bt_sched[i] = ratio * betas[i];
+            c1[i] = sqrtf(1.0f / alphas[i]);
+            c2[i] = (1.0f - alphas[i]) / sqrtf(1.0f - abar[i]);
+            sigma[i] = sqrtf(bt_sampler[i]);
+            sigma_beta[i] = sqrtf(betas[i]);
+        }
+    }
+};
+const Schedule& schedule() {
+    static const Schedule s;
+    return s;
+}
+
+unsigned short host_f2bf(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// expected shapes by reference state_dict name (models/uvit.py:228-336)
+bool expected_shape(const dd_model* m, const std::string& name, std::vector<int64_t>& shp) {
+    const int64_t D = m->D, C = m->cfg.in_chans, P = m->cfg.patch_size, hid = m->hidden;
+    auto is = [&](const char* s) { return name == s; };
+    if (is("pos_embed")) { shp = {1, m->L, D}; return true; }
+    if (is("patch_embed.proj.weight")) { shp = {D, C, P, P}; return true; }
+    if (is("patch_embed.proj.bias")) { shp = {D}; return true; }
+    if (is("label_emb.weight")) { if (m->cfg.num_classes <= 0) return false; shp = {m->cfg.num_classes, D}; return true; }
+    if (is("norm.weight") || is("norm.bias")) { shp = {D}; return true; }
+    if (is("decoder_pred.weight")) { shp = {m->pd, D}; return true; }
+    if (is("decoder_pred.bias")) { shp = {m->pd}; return true; }
+    if (is("final_layer.weight")) { shp = {C, C, 3, 3}; return true; }
+    if (is("final_layer.bias")) { shp = {C}; return true; }
+    std::string rest;
+    bool out_blk = false;
+    auto strip = [&](const char* pre, bool indexed) -> bool {
+        const size_t n = std::strlen(pre);
+        if (name.compare(0, n, pre) != 0) return false;
+        size_t p = n;
+        if (indexed) {
+            size_t q = p;
+            while (q < name.size() && name[q] >= '0' && name[q] <= '9') ++q;
+            if (q == p || q >= name.size() || name[q] != '.') return false;
+            const int idx = std::atoi(name.substr(p, q - p).c_str());
+            if (idx >= m->half_depth) return false;
+            p = q + 1;
+        }
+        rest = name.substr(p);
+        return true;
+    };
+    if (strip("in_blocks.", true)) out_blk = false;
+    else if (strip("out_blocks.", true)) out_blk = true;
+    else if (strip("mid_block.", false)) out_blk = false;
+    else return false;
+    if (rest == "norm1.weight" || rest == "norm1.bias" || rest == "norm2.weight" || rest == "norm2.bias" ||
+        rest == "attn.proj.bias" || rest == "mlp.fc2.bias") { shp = {D}; return true; }
+    if (rest == "attn.qkv.weight") { shp = {3 * D, D}; return true; }
+    if (rest == "attn.proj.weight") { shp = {D, D}; return true; }
+    if (rest == "mlp.fc1.weight") { shp = {hid, D}; return true; }
+    if (rest == "mlp.fc1.bias") { shp = {hid}; return true; }
+    if (rest == "mlp.fc2.weight") { shp = {D, hid}; return true; }
+    if (out_blk && rest == "skip_linear.weight") { shp = {D, 2 * D}; return true; }
+    if (out_blk && rest == "skip_linear.bias") { shp = {D}; return true; }
+    return false;
+}
+
+std::vector<std::string> required_names(const dd_model* m) {
+    std::vector<std::string> v = {"pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias", "norm.weight",
+                                  "norm.bias", "decoder_pred.weight", "decoder_pred.bias", "final_layer.weight",
+                                  "final_layer.bias"};
+    if (m->cfg.num_classes > 0) v.push_back("label_emb.weight");
+    auto blk = [&](const std::string& p, bool skip) {
+        for (const char* s : {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.proj.weight", "attn.proj.bias",
+                              "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                              "mlp.fc2.bias"})
+            v.push_back(p + s);
+        if (skip) { v.push_back(p + "skip_linear.weight"); v.push_back(p + "skip_linear.bias"); }
+    };
+    for (int i = 0; i < m->half_depth; ++i) blk("in_blocks." + std::to_string(i) + ".", false);
+    blk("mid_block.", false);
+    for (int i = 0; i < m->half_depth; ++i) blk("out_blocks." + std::to_string(i) + ".", true);
+    return v;
+}
+
+// ---- the forward: tokens -> blocks -> decoder_pred patches (m->dec) ---------------------------
+template <typename T>
+int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s) {
+    dd_ctx* c = m->ctx;
+    const int D = m->D, L = m->L, M = B * L;
+    const int Mp = round_up(M, 256);
+    EmbedArgs ea{x_img, m->emb_wt, m->emb_b, m->pos, m->label, (const long long*)y_dev, t_vec, c->st, m->x,
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, D, L, m->extras,
+                 m->cfg.num_classes, m->cfg.normalize_timesteps, Mp};
+    DD_HIP(c, launch_embed(ea, s));
+
+    T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
+    const int nb = (int)m->blocks.size();
+    for (int bi = 0; bi < nb; ++bi) {
+        const BlockW& w = m->blocks[bi];
+        const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
+        if (is_out) {
+            const int oi = bi - m->half_depth - 1;
+            const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
+            GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s));
+        }
+        DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));
+        {
+            GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, nullptr, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
+            DD_HIP(c, launch_gemm<T>(g, EPI_STORE, s));
+        }
+        DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
+        {
+            GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
+        }
+        DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));
+        {
+            GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hidden};
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s));
+        }
+        {
+            // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
+            // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
+            T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
+            GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
+                          m->hidden, 0, D};
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
+        }
+    }
+    HeadArgs ha{m->x, m->norm_g, m->norm_b, m->wdt, m->bdec, m->dec, B, L, m->N, m->extras, D, m->pd, m->pdp};
+    DD_HIP(c, launch_head_decode(ha, s));
+    return DD_OK;
+}
+
+int run_model(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s) {
+    return m->prec == DD_PREC_BF16 ? run_backbone<bf16_t>(m, x_img, t_vec, y_dev, B, s)
+                                   : run_backbone<float>(m, x_img, t_vec, y_dev, B, s);
+}
+
+int check_call(dd_ctx* c, dd_model* m, int B, const int64_t* y_dev) {
+    if (!c || !m) return DD_ERR_INVALID;
+    if (m->ctx != c) return fail(c, DD_ERR_INVALID, "model belongs to another context");
+    if (!m->finalized) return fail(c, DD_ERR_STATE, "dd_model_finalize has not been called");
+    if (B < 1 || B > m->cfg.max_batch) return fail(c, DD_ERR_INVALID, "batch size outside [1, max_batch]");
+    if (m->cfg.num_classes > 0 && !y_dev)
+        return fail(c, DD_ERR_INVALID, "class-conditional model called without labels (pos_embed has L=extras+N rows)");
+    if (m->cfg.num_classes <= 0 && y_dev)
+        return fail(c, DD_ERR_INVALID, "unconditional model called with labels");
+    return DD_OK;
+}
+
+// one sampling step enqueued on s: x <- update(x, model(x, t)) ; t comes from ctx->st
+int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int noise_mode, const float* z_dev,
+                 int variance, float* eps_out, int B, hipStream_t s) {
+    int rc = run_model(m, x_dev, nullptr, y_dev, B, s);
+    if (rc) return rc;
+    FinalArgs fa{m->dec, m->wconv, m->bconv, x_dev, z_dev, eps_out, x_dev, c->st, c->coef,
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, noise_mode, variance};
+    DD_HIP(c, launch_final(fa, s));
+    return DD_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+int dd_schedule_table(int which, float* out) {
+    if (!out) return DD_ERR_INVALID;
+    const Schedule& s = schedule();
+    const float* src = nullptr;
+    switch (which) {
+        case 0: src = s.betas; break;
+        case 1: src = s.alphas; break;
+        case 2: src = s.abar; break;
+        case 3: src = s.abar_prev; break;
+        case 4: src = s.bt_sampler; break;
+        case 5: src = s.bt_sched; break;
+        case 6: src = s.c1; break;
+        case 7: src = s.c2; break;
+        case 8: src = s.sigma; break;
+        default: return DD_ERR_INVALID;
+    }
+    std::memcpy(out, src, 1000 * sizeof(float));
+    return DD_OK;
+}
+
+int dd_ctx_create(int device, dd_ctx** out) {
+    if (!out) return DD_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DD_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return DD_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DD_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DD_ERR_UNSUPPORTED;  // gfx950 code objects only
+    dd_ctx* c = new (std::nothrow) dd_ctx();
+    if (!c) return DD_ERR_NOMEM;
+    c->device = device;
+    const Schedule& s = schedule();
+    for (int i = 0; i < 1000; ++i) c->coef_host[i] = StepCoef{s.c1[i], s.c2[i], s.sigma[i], s.sigma_beta[i]};
+    bool ok = hipMalloc(&c->st, sizeof(StepState)) == hipSuccess && hipMalloc(&c->coef, sizeof(StepCoef) * 1000) == hipSuccess &&
+              hipMemcpy(c->coef, c->coef_host, sizeof(StepCoef) * 1000, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemset(c->st, 0, sizeof(StepState)) == hipSuccess;
+    for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
+         init_rowops_kernels() == hipSuccess;
+    if (!ok) { dd_ctx_destroy(c); return DD_ERR_HIP; }
+    *out = c;
+    return DD_OK;
+}
+
+void dd_ctx_destroy(dd_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipFree(c->st);
+    if (c->coef) (void)hipFree(c->coef);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* dd_last_error(dd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int dd_sync(dd_ctx* c, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    DD_HIP(c, hipStreamSynchronize((hipStream_t)stream));
+    return DD_OK;
+}
+
+int dd_model_create(dd_ctx* c, const dd_config* cfg, dd_model** out) {
+    if (!c || !cfg || !out) return DD_ERR_INVALID;
+    *out = nullptr;
+    const dd_config& g = *cfg;
+    if (g.img_size <= 0 || g.patch_size <= 0 || g.img_size % g.patch_size) return fail(c, DD_ERR_INVALID, "img_size must be a positive multiple of patch_size");
+    if (g.num_heads <= 0 || g.embed_dim != g.num_heads * 64) return fail(c, DD_ERR_UNSUPPORTED, "kernels require head_dim == 64 (all shipped configs)");
+    if (g.depth < 1 || g.depth % 2 != 1) return fail(c, DD_ERR_INVALID, "depth must be odd");
+    if (g.in_chans < 1 || g.in_chans > 4) return fail(c, DD_ERR_UNSUPPORTED, "in_chans must be 1..4");
+    if (g.embed_dim > 1024) return fail(c, DD_ERR_UNSUPPORTED, "embed_dim must be <= 1024");
+    if (g.max_batch < 1) return fail(c, DD_ERR_INVALID, "max_batch must be >= 1");
+    dd_model* m = new (std::nothrow) dd_model();
+    if (!m) return fail(c, DD_ERR_NOMEM, "out of host memory");
+    m->ctx = c; m->cfg = g;
+    m->D = g.embed_dim; m->H = g.num_heads;
+    m->N = (g.img_size / g.patch_size) * (g.img_size / g.patch_size);
+    m->extras = g.num_classes > 0 ? 2 : 1;
+    m->L = m->N + m->extras;
+    m->pd = g.patch_size * g.patch_size * g.in_chans;
+    m->pdp = round_up(m->pd, 8);
+    m->hidden = g.embed_dim * (g.mlp_ratio > 0 ? g.mlp_ratio : 4);
+    m->half_depth = g.depth / 2;
+    m->Mp_max = round_up(g.max_batch * m->L, 256);
+    if (m->L > 288) { delete m; return fail(c, DD_ERR_UNSUPPORTED, "sequence length must be <= 288 tokens"); }
+    if (m->pd > 64) { delete m; return fail(c, DD_ERR_UNSUPPORTED, "patch_size^2 * in_chans must be <= 64"); }
+    *out = m;
+    return DD_OK;
+}
+
+int dd_model_set_param(dd_model* m, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!m || !name || !host || !shape || ndim < 1) return DD_ERR_INVALID;
+    dd_ctx* c = m->ctx;
+    if (m->finalized) return fail(c, DD_ERR_STATE, "model already finalized");
+    std::vector<int64_t> want;
+    if (!expected_shape(m, name, want)) return fail(c, DD_ERR_NOT_FOUND, std::string("unexpected key in state_dict: ") + name);
+    std::vector<int64_t> got(shape, shape + ndim);
+    if (got != want) {
+        std::string msg = std::string("size mismatch for ") + name + ": expected [";
+        for (size_t i = 0; i < want.size(); ++i) msg += (i ? "," : "") + std::to_string(want[i]);
+        msg += "], got [";
+        for (size_t i = 0; i < got.size(); ++i) msg += (i ? "," : "") + std::to_string(got[i]);
+        return fail(c, DD_ERR_INVALID, msg + "]");
+    }
+    size_t n = 1;
+    for (auto d : want) n *= (size_t)d;
+    HostParam& p = m->params[name];
+    p.data.assign(host, host + n);
+    p.shape = want;
+    p.set = true;
+    return DD_OK;
+}
+
+int64_t dd_model_num_params(const dd_model* m) {
+    if (!m) return 0;
+    int64_t n = 0;
+    for (auto& kv : m->params) n += (int64_t)kv.second.data.size();
+    return n;
+}
+
+int dd_model_finalize(dd_model* m, int precision) {
+    if (!m) return DD_ERR_INVALID;
+    dd_ctx* c = m->ctx;
+    if (m->finalized) return fail(c, DD_ERR_STATE, "model already finalized");
+    if (precision != DD_PREC_BF16 && precision != DD_PREC_FP32) return fail(c, DD_ERR_INVALID, "unknown precision");
+    for (const std::string& nm : required_names(m)) {
+        auto it = m->params.find(nm);
+        if (it == m->params.end() || !it->second.set) return fail(c, DD_ERR_NOT_FOUND, "missing key in state_dict: " + nm);
+    }
+    DD_HIP(c, hipSetDevice(c->device));
+    m->prec = precision;
+    m->esize = precision == DD_PREC_BF16 ? 2 : 4;
+    const size_t es = m->esize;
+    const int D = m->D, hid = m->hidden, L = m->L;
+
+    // ---- pack weights into one arena: fp32 vectors/tables + T-typed GEMM matrices
+    std::vector<char> host;
+    auto align = [&]() { host.resize((host.size() + 255) / 256 * 256); };
+    auto put_f32 = [&](const float* src, size_t n) -> size_t {
+        align(); const size_t off = host.size(); host.resize(off + n * 4); std::memcpy(&host[off], src, n * 4); return off;
+    };
+    auto put_mat = [&](const std::vector<float>& src) -> size_t {
+        align(); const size_t off = host.size(); host.resize(off + src.size() * es);
+        if (es == 4) std::memcpy(&host[off], src.data(), src.size() * 4);
+        else { unsigned short* d = (unsigned short*)&host[off]; for (size_t i = 0; i < src.size(); ++i) d[i] = host_f2bf(src[i]); }
+        return off;
+    };
+    auto P = [&](const std::string& nm) -> const std::vector<float>& { return m->params[nm].data; };
+
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w; bool skip; };
+    std::vector<BlockOff> boffs;
+    auto pack_block = [&](const std::string& p, bool skip) {
+        BlockOff o{};
+        o.skip = skip;
+        o.ln1_g = put_f32(P(p + "norm1.weight").data(), D); o.ln1_b = put_f32(P(p + "norm1.bias").data(), D);
+        o.ln2_g = put_f32(P(p + "norm2.weight").data(), D); o.ln2_b = put_f32(P(p + "norm2.bias").data(), D);
+        o.proj_b = put_f32(P(p + "attn.proj.bias").data(), D);
+        o.fc1_b = put_f32(P(p + "mlp.fc1.bias").data(), hid); o.fc2_b = put_f32(P(p + "mlp.fc2.bias").data(), D);
+        o.qkv_w = put_mat(P(p + "attn.qkv.weight")); o.proj_w = put_mat(P(p + "attn.proj.weight"));
+        o.fc1_w = put_mat(P(p + "mlp.fc1.weight")); o.fc2_w = put_mat(P(p + "mlp.fc2.weight"));
+        if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
+        boffs.push_back(o);
+    };
+    for (int i = 0; i < m->half_depth; ++i) pack_block("in_blocks." + std::to_string(i) + ".", false);
+    pack_block("mid_block.", false);
+    for (int i = 0; i < m->half_depth; ++i) pack_block("out_blocks." + std::to_string(i) + ".", true);
+
+    // patch-embed weight [D, pd] -> transposed [pd, D] ; decoder_pred [pd, D] -> transposed, padded [D, pdp]
+    std::vector<float> wt((size_t)m->pd * D), wdt((size_t)D * m->pdp, 0.f);
+    const std::vector<float>& pe = P("patch_embed.proj.weight");
+    for (int d = 0; d < D; ++d) for (int k = 0; k < m->pd; ++k) wt[(size_t)k * D + d] = pe[(size_t)d * m->pd + k];
+    const std::vector<float>& dw = P("decoder_pred.weight");
+    for (int j = 0; j < m->pd; ++j) for (int d = 0; d < D; ++d) wdt[(size_t)d * m->pdp + j] = dw[(size_t)j * D + d];
+    const size_t o_wt = put_f32(wt.data(), wt.size()), o_eb = put_f32(P("patch_embed.proj.bias").data(), D);
+    const size_t o_pos = put_f32(P("pos_embed").data(), (size_t)L * D);
+    const size_t o_lab = m->cfg.num_classes > 0 ? put_f32(P("label_emb.weight").data(), (size_t)m->cfg.num_classes * D) : 0;
+    const size_t o_ng = put_f32(P("norm.weight").data(), D), o_nb = put_f32(P("norm.bias").data(), D);
+    const size_t o_wdt = put_f32(wdt.data(), wdt.size()), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
+    const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
+    const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
+    align();
+
+    DD_HIP(c, hipMalloc((void**)&m->warena, host.size()));
+    DD_HIP(c, hipMemcpy(m->warena, host.data(), host.size(), hipMemcpyHostToDevice));
+    auto F = [&](size_t off) { return (const float*)(m->warena + off); };
+    auto V = [&](size_t off) { return (const void*)(m->warena + off); };
+    for (const BlockOff& o : boffs) {
+        BlockW w{F(o.ln1_g), F(o.ln1_b), F(o.ln2_g), F(o.ln2_b), F(o.proj_b), F(o.fc1_b), F(o.fc2_b),
+                 o.skip ? F(o.skip_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
+                 o.skip ? V(o.skip_w) : nullptr};
+        m->blocks.push_back(w);
+    }
+    m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
+    m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdt = F(o_wdt); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
+
+    // ---- activation workspace (HBM-resident for the life of the model)
+    const size_t Mp = (size_t)m->Mp_max;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(Mp * 3 * D * es);
+    const size_t o_hid = take(Mp * hid * es), o_xb = take(Mp * D * es);
+    std::vector<size_t> o_sk;
+    for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
+    const size_t o_dec = take((size_t)m->cfg.max_batch * m->N * m->pd * 4);
+    DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
+    DD_HIP(c, hipMemset(m->wsarena, 0, off));
+    m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
+    m->hid = m->wsarena + o_hid; m->xb = m->wsarena + o_xb; m->dec = (float*)(m->wsarena + o_dec);
+    for (size_t o : o_sk) m->skips.push_back(m->wsarena + o);
+
+    // host copies are no longer needed
+    for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
+    m->finalized = true;
+    return DD_OK;
+}
+
+void dd_model_destroy(dd_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    if (m->graph) (void)hipGraphExecDestroy(m->graph);
+    if (m->warena) (void)hipFree(m->warena);
+    if (m->wsarena) (void)hipFree(m->wsarena);
+    delete m;
+}
+
+int dd_forward(dd_ctx* c, dd_model* m, const float* x_dev, float t, const float* t_dev, const int64_t* y_dev,
+               float* eps_dev, int B, void* stream) {
+    int rc = check_call(c, m, B, y_dev);
+    if (rc) return rc;
+    if (!x_dev || !eps_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    DD_HIP(c, launch_set_state_float(c->st, t, s));
+    rc = run_model(m, x_dev, t_dev, y_dev, B, s);
+    if (rc) return rc;
+    FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, DD_NOISE_NONE, 0};
+    DD_HIP(c, launch_final(fa, s));
+    return DD_OK;
+}
+
+int dd_ddpm_step(dd_ctx* c, const float* x_dev, const float* eps_dev, const float* z_dev, int t, int variance,
+                 float* x_out_dev, int64_t n, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    if (!x_dev || !eps_dev || !x_out_dev || n < 0) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (t < 0 || t > 999) return fail(c, DD_ERR_INVALID, "timestep outside [0, 999]");
+    StepCoef cf = c->coef_host[t];
+    if (variance == DD_VAR_BETA) cf.sigma_tilde = cf.sigma_beta;
+    const int use_noise = (t > 0 && z_dev) ? 1 : 0;
+    if (n == 0) return DD_OK;
+    DD_HIP(c, launch_ddpm_step(x_dev, eps_dev, z_dev, x_out_dev, cf, use_noise, (long long)n, (hipStream_t)stream));
+    return DD_OK;
+}
+
+int dd_sample_step(dd_ctx* c, dd_model* m, float* x_dev, int t, const int64_t* y_dev, int noise_mode, const float* z_dev,
+                   uint64_t seed, int variance, float* eps_out_dev, int B, void* stream) {
+    int rc = check_call(c, m, B, y_dev);
+    if (rc) return rc;
+    if (!x_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (t < 0 || t > 999) return fail(c, DD_ERR_INVALID, "timestep outside [0, 999]");
+    if (noise_mode == DD_NOISE_BUFFER && !z_dev && t > 0) return fail(c, DD_ERR_INVALID, "DD_NOISE_BUFFER needs z_dev");
+    hipStream_t s = (hipStream_t)stream;
+    DD_HIP(c, launch_set_state(c->st, t, (unsigned long long)seed, s));
+    return enqueue_step(c, m, x_dev, y_dev, noise_mode, z_dev, variance, eps_out_dev, B, s);
+}
+
+int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
+    if (!c || !a) return DD_ERR_INVALID;
+    int rc = check_call(c, a->first, a->B, a->y_dev);
+    if (rc) return rc;
+    if (a->late && (rc = check_call(c, a->late, a->B, a->y_dev))) return rc;
+    if (!a->x_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (a->t_start > 999 || a->t_end < 0 || a->t_end > a->t_start) return fail(c, DD_ERR_INVALID, "need 999 >= t_start >= t_end >= 0");
+    if (a->noise_mode != DD_NOISE_PHILOX && a->noise_mode != DD_NOISE_NONE)
+        return fail(c, DD_ERR_INVALID, "dd_sample generates noise on the device; for host noise drive dd_sample_step");
+    if (a->late) {
+        const dd_config &f = a->first->cfg, &l = a->late->cfg;
+        if (f.img_size != l.img_size || f.in_chans != l.in_chans) return fail(c, DD_ERR_INVALID, "first and late model disagree on image shape");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool switching = a->late && a->t_switch > 0 && a->t_switch <= 1000;
+    const int t_sw = 1000 - a->t_switch;  // the late model takes over AFTER this step (sampler.py:135-136)
+
+    auto get_graph = [&](dd_model* m) -> int {
+        GraphKey key{a->x_dev, a->y_dev, a->B, a->noise_mode, a->variance};
+        if (m->graph && m->gkey == key) return DD_OK;
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        hipGraph_t g = nullptr;
+        DD_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int r = enqueue_step(c, m, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s);
+        hipError_t e1 = r ? hipSuccess : launch_advance_state(c->st, s);
+        hipError_t e2 = hipStreamEndCapture(s, &g);
+        if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+        if (e1 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail_hip(c, e1, "advance_state"); }
+        if (e2 != hipSuccess) return fail_hip(c, e2, "hipStreamEndCapture");
+        hipError_t e3 = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e3 != hipSuccess) { m->graph = nullptr; return fail_hip(c, e3, "hipGraphInstantiate"); }
+        m->gkey = key;
+        return DD_OK;
+    };
+
+    if (a->use_graph) {
+        if ((rc = get_graph(a->first))) return rc;
+        if (switching && (rc = get_graph(a->late))) return rc;
+    }
+    DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
+    DD_HIP(c, hipEventRecord(c->ev[0], s));
+    bool marked = false;
+    dd_model* cur = a->first;
+    for (int t = a->t_start; t >= a->t_end; --t) {
+        if (a->use_graph) {
+            DD_HIP(c, hipGraphLaunch(cur->graph, s));
+        } else {
+            rc = enqueue_step(c, cur, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s);
+            if (rc) return rc;
+            DD_HIP(c, launch_advance_state(c->st, s));
+        }
+        if (switching && t == t_sw) {
+            cur = a->late;
+            DD_HIP(c, hipEventRecord(c->ev[1], s));
+            marked = true;
+        }
+    }
+    if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
+    DD_HIP(c, hipEventRecord(c->ev[2], s));
+    return DD_OK;
+}
+
+int dd_last_sample_timing(dd_ctx* c, float out3[3]) {
+    if (!c || !out3) return DD_ERR_INVALID;
+    DD_HIP(c, hipEventSynchronize(c->ev[2]));
+    DD_HIP(c, hipEventElapsedTime(&out3[0], c->ev[0], c->ev[2]));
+    DD_HIP(c, hipEventElapsedTime(&out3[1], c->ev[0], c->ev[1]));
+    DD_HIP(c, hipEventElapsedTime(&out3[2], c->ev[1], c->ev[2]));
+    return DD_OK;
+}
+
+int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float* ms_out, double* flops_out) {
+    int rc = check_call(c, m, B, m && m->cfg.num_classes > 0 ? (const int64_t*)1 : nullptr);
+    if (rc) return rc;
+    if (iters < 1 || !ms_out) return fail(c, DD_ERR_INVALID, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int M = B * m->L, D = m->D;
+    const BlockW& w = m->blocks[0];
+    auto once = [&]() -> hipError_t {
+        if (m->prec == DD_PREC_BF16) {
+            GemmArgs<bf16_t> g{(const bf16_t*)m->h, nullptr, (const bf16_t*)w.fc1_w, w.fc1_b, nullptr, (bf16_t*)m->hid,
+                               M, m->hidden, D, D, D, 0, m->hidden};
+            return launch_gemm<bf16_t>(g, EPI_BIAS_GELU, s);
+        }
+        GemmArgs<float> g{(const float*)m->h, nullptr, (const float*)w.fc1_w, w.fc1_b, nullptr, (float*)m->hid,
+                          M, m->hidden, D, D, D, 0, m->hidden};
+        return launch_gemm<float>(g, EPI_BIAS_GELU, s);
+    };
+    DD_HIP(c, once());
+    hipEvent_t e0, e1;
+    DD_HIP(c, hipEventCreate(&e0));
+    DD_HIP(c, hipEventCreate(&e1));
+    DD_HIP(c, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) DD_HIP(c, once());
+    DD_HIP(c, hipEventRecord(e1, s));
+    DD_HIP(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    DD_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms / (float)iters;
+    if (flops_out) *flops_out = 2.0 * (double)M * (double)m->hidden * (double)D;
+    return DD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Internal declarations shared by the HIP translation units of libduodiff.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dd {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __builtin_bit_cast(float, ((unsigned)b) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kPerChunk = 8;
+    __device__ static __forceinline__ bf16_t from_f32(float v) { return f2bf(v); }
+    __device__ static __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
+};
+
+// Device-resident per-step state, so that a captured hipGraph replays without parameter
+// patching: kernels read t from here, the last node of a step decrements it.
+struct StepState {
+    int t;            // current timestep (999 .. 0)
+    float t_model;    // what the model sees: t or t/1000 is derived in the embed kernel
+    unsigned long long seed;
+    int pad;
+};
+
+// per-timestep update coefficients, x' = c1 (x - c2 eps) + sigma z
+struct StepCoef {
+    float c1, c2, sigma_tilde, sigma_beta;
+};
+
+enum GemmEpilogue {
+    EPI_STORE = 0,        // out = T(acc)                                  (qkv)
+    EPI_BIAS_GELU = 1,    // out = T(gelu_erf(acc + bias))                 (fc1)
+    EPI_BIAS_RESID = 2,   // x += acc + bias ; optional out = T(x)         (proj, fc2)
+    EPI_BIAS_SET = 3      // x  = acc + bias                               (skip_linear)
+};
+
+// C[M,N] = [A | A2][M,K] . W[N,K]^T ; A holds k < K1, A2 holds the rest (concat-free skip GEMM).
+template <typename T>
+struct GemmArgs {
+    const T* A;
+    const T* A2;
+    const T* W;        // [N, K] row-major (nn.Linear layout)
+    const float* bias; // [N] or null
+    float* xres;       // fp32 [Mp, N] residual stream (EPI_BIAS_RESID / EPI_BIAS_SET)
+    T* out;            // [Mp, ldo] or null
+    int M, N, K, K1;
+    int lda, lda2, ldo;
+};
+
+template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s);
+
+struct EmbedArgs {
+    const float* x_img;      // [B,C,S,S]
+    const float* wt;         // [pd, D]  patch-embed weight, transposed
+    const float* bias;       // [D]
+    const float* pos;        // [L, D]
+    const float* label_emb;  // [num_classes, D] or null
+    const long long* y;      // [B] or null
+    const float* t_vec;      // [B] per-row timesteps or null (then st->t_model)
+    const StepState* st;
+    float* x_tok;            // [Mp, D]
+    int B, C, S, P, D, L, extras, num_classes, normalize, Mp;
+};
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+
+template <typename T>
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, T* out,
+                            int rows, int D, hipStream_t s);
+
+template <typename T>
+hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
+
+struct HeadArgs {
+    const float* x_tok;   // [Mp, D]
+    const float* gamma;   // final norm
+    const float* beta;
+    const float* wdt;     // [D, pdp] decoder_pred weight transposed, pd padded to pdp
+    const float* bdec;    // [pd]
+    float* dec;           // [B*N, pd]
+    int B, L, N, extras, D, pd, pdp;
+};
+hipError_t launch_head_decode(const HeadArgs& a, hipStream_t s);
+
+struct FinalArgs {
+    const float* dec;      // [B*N, pd]
+    const float* wconv;    // [C, C, 3, 3]
+    const float* bconv;    // [C]
+    const float* x_in;     // [B,C,S,S] or null (forward only)
+    const float* z;        // [B,C,S,S] or null
+    float* eps_out;        // or null
+    float* x_out;          // or null (may alias x_in)
+    const StepState* st;
+    const StepCoef* coef;  // [1000]
+    int B, C, S, P, noise_mode, variance;
+};
+hipError_t launch_final(const FinalArgs& a, hipStream_t s);
+
+hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, float* out,
+                            StepCoef c, int use_noise, long long n, hipStream_t s);
+hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
+hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
+hipError_t launch_advance_state(StepState* st, hipStream_t s);
+
+}  // namespace dd

@@ -1,0 +1,181 @@
+"""Thin object layer over the C ABI: one Context per (process, GPU), Models built from a
+reference-style state_dict.  torch tensors are containers for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .config import ModelParams
+
+_ERR_CLASS = {
+    L.DD_ERR_INVALID: ValueError,
+    L.DD_ERR_NOT_FOUND: KeyError,
+    L.DD_ERR_STATE: RuntimeError,
+    L.DD_ERR_HIP: RuntimeError,
+    L.DD_ERR_NOMEM: MemoryError,
+    L.DD_ERR_UNSUPPORTED: NotImplementedError,
+}
+
+PRECISIONS = {"bf16": L.DD_PREC_BF16, "fp32": L.DD_PREC_FP32}
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Context:
+    """dd_ctx: bound to one device.  Creation fails loudly without a gfx950 GPU."""
+
+    _per_device = {}
+
+    def __init__(self, device=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.EngineUnavailable("no GPU visible: the DuoDiff engine runs only on MI355X (gfx950)")
+        self.device = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.dd_ctx_create(int(self.device), C.byref(h))
+        if rc != L.DD_OK:
+            raise L.EngineUnavailable(f"dd_ctx_create(device={self.device}) failed with status {rc} "
+                                      "(needs a gfx950 device and a working HIP runtime)")
+        self.handle = h
+
+    @classmethod
+    def get(cls, device=None):
+        idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+        if idx not in cls._per_device:
+            cls._per_device[idx] = cls(idx)
+        return cls._per_device[idx]
+
+    def check(self, rc):
+        if rc == L.DD_OK:
+            return
+        msg = self.lib.dd_last_error(self.handle)
+        msg = msg.decode() if msg else f"status {rc}"
+        raise _ERR_CLASS.get(rc, RuntimeError)(msg)
+
+    def sync(self, stream=None):
+        self.check(self.lib.dd_sync(self.handle, _stream_ptr(stream)))
+
+    def ddpm_step(self, x, eps, z, t, variance="beta_tilde", out=None, stream=None):
+        """x' = postprocessing(eps, x, t) (reference sampler.py:47-56) on device tensors."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        var = L.DD_VAR_BETA if variance == "beta" else L.DD_VAR_BETA_TILDE
+        self.check(self.lib.dd_ddpm_step(self.handle, _ptr(x), _ptr(eps.contiguous()),
+                                         _ptr(z.contiguous() if z is not None else None), int(t), var,
+                                         _ptr(out), x.numel(), _stream_ptr(stream)))
+        return out
+
+    def last_sample_timing(self):
+        buf = (C.c_float * 3)()
+        self.check(self.lib.dd_last_sample_timing(self.handle, buf))
+        return tuple(buf)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.dd_ctx_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+def schedule_tables():
+    """The engine's own schedule tables (host arithmetic, usable without a GPU)."""
+    lib = L.load()
+    names = ["betas", "alphas", "alphas_bar", "alphas_bar_previous", "betas_tilde",
+             "betas_tilde_scheduler", "c1", "c2", "sigma"]
+    out = {}
+    for i, n in enumerate(names):
+        a = np.empty(1000, np.float32)
+        rc = lib.dd_schedule_table(i, a.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != L.DD_OK:
+            raise RuntimeError(f"dd_schedule_table({i}) -> {rc}")
+        out[n] = a
+    return out
+
+
+class Model:
+    """dd_model: U-ViT weights packed on the device + its activation workspace."""
+
+    def __init__(self, ctx: Context, mp: ModelParams, max_batch: int):
+        self.ctx, self.mp, self.max_batch = ctx, mp, int(max_batch)
+        cfg = L.dd_config(mp.img_size, mp.patch_size, mp.in_chans, mp.embed_dim, mp.depth, mp.num_heads,
+                          mp.mlp_ratio, mp.num_classes, int(mp.normalize_timesteps), self.max_batch)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dd_model_create(ctx.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.finalized = False
+        self.precision = None
+
+    def set_param(self, name, tensor):
+        t = tensor.detach().to("cpu", torch.float32).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        self.ctx.check(self.ctx.lib.dd_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()),
+                                                       shape, t.dim()))
+
+    def finalize(self, precision="bf16"):
+        with torch.cuda.device(self.ctx.device):
+            self.ctx.check(self.ctx.lib.dd_model_finalize(self.handle, PRECISIONS[precision]))
+        self.finalized, self.precision = True, precision
+
+    def forward(self, x, t, y=None, out=None, t_vec=None, stream=None):
+        """eps = model(x, t, y).  t: the common timestep; t_vec: optional [B] fp32 device tensor."""
+        B = x.shape[0]
+        out = torch.empty_like(x) if out is None else out
+        self.ctx.check(self.ctx.lib.dd_forward(self.ctx.handle, self.handle, _ptr(x), float(t), _ptr(t_vec),
+                                               _ptr(y), _ptr(out), B, _stream_ptr(stream)))
+        return out
+
+    def sample_step(self, x, t, y=None, z=None, noise="buffer", seed=0, variance="beta_tilde", eps_out=None,
+                    stream=None):
+        mode = {"none": L.DD_NOISE_NONE, "buffer": L.DD_NOISE_BUFFER, "philox": L.DD_NOISE_PHILOX}[noise]
+        if mode == L.DD_NOISE_BUFFER and z is None:
+            mode = L.DD_NOISE_NONE
+        var = L.DD_VAR_BETA if variance == "beta" else L.DD_VAR_BETA_TILDE
+        self.ctx.check(self.ctx.lib.dd_sample_step(self.ctx.handle, self.handle, _ptr(x), int(t), _ptr(y), mode,
+                                                   _ptr(z), int(seed), var, _ptr(eps_out), x.shape[0],
+                                                   _stream_ptr(stream)))
+        return x
+
+    def bench_gemm(self, B, iters=20, stream=None):
+        ms, fl = C.c_float(), C.c_double()
+        self.ctx.check(self.ctx.lib.dd_bench_gemm(self.ctx.handle, self.handle, int(B), int(iters),
+                                                  _stream_ptr(stream), C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.ctx.lib.dd_model_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+def sample_loop(ctx: Context, first: Model, late, x, *, t_switch=0, t_start=999, t_end=0, y=None, seed=0,
+                noise="philox", variance="beta_tilde", use_graph=True, stream=None):
+    """dd_sample: the whole DDPM loop on the device (hipGraph replay per backbone), in place on x."""
+    args = L.dd_sample_args()
+    args.first = first.handle
+    args.late = late.handle if late is not None else None
+    args.t_switch = int(t_switch) if t_switch and np.isfinite(t_switch) else 0
+    args.t_start, args.t_end = int(t_start), int(t_end)
+    args.variance = L.DD_VAR_BETA if variance == "beta" else L.DD_VAR_BETA_TILDE
+    args.noise_mode = {"none": L.DD_NOISE_NONE, "philox": L.DD_NOISE_PHILOX}[noise]
+    args.use_graph = int(bool(use_graph))
+    args.seed = int(seed)
+    args.y_dev = y.data_ptr() if y is not None else None
+    args.x_dev = x.data_ptr()
+    args.B = x.shape[0]
+    ctx.check(ctx.lib.dd_sample(ctx.handle, C.byref(args), _stream_ptr(stream)))
+    return x

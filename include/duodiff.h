@@ -1,0 +1,151 @@
+/*
+ * duodiff.h -- C ABI of libduodiff.so: the MI355X (gfx950) DuoDiff sampling engine.
+ *
+ * The reference (razvanmatisan/duodiff) is pure Python and has no FFI; its boundary
+ * for the hot path is a pair of Python call signatures:
+ *
+ *     eps = model(x, time_tensor, y)            sampler.py:130-132, ddpm_core.py:150-152
+ *     x   = postprocessing(eps, x, t)           sampler.py:133 -> sampler.py:47-56
+ *
+ * driven 1000 times by get_samples (sampler.py:82-155) with the backbone switch
+ * at t == 1000 - t_switch (sampler.py:135-136).  This header is what a ctypes stub
+ * on the reference side binds to replace exactly those calls.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, ints.  No torch / HIP types in signatures; a stream is
+ *     passed as void* (a hipStream_t; NULL = the null stream).
+ *   - *_dev pointers are DEVICE pointers owned by the caller (e.g. torch-allocated).
+ *     Images are fp32 NCHW contiguous, exactly like the reference's tensors.
+ *   - every entry returns 0 on success, a negative dd_status on failure; the message is
+ *     kept per context (dd_last_error).  No C++ exception and no abort() crosses the ABI.
+ *   - a dd_ctx is bound to one device and is not re-entrant; all device work is enqueued
+ *     asynchronously on the caller's stream, only dd_sync blocks.
+ *   - there is NO CPU fallback: without a usable GPU dd_ctx_create fails.
+ */
+#ifndef DUODIFF_H
+#define DUODIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+typedef struct dd_ctx dd_ctx;
+typedef struct dd_model dd_model;
+
+typedef enum dd_status {
+    DD_OK = 0,
+    DD_ERR_INVALID = -1,      /* bad argument / shape mismatch   (Python: ValueError / RuntimeError) */
+    DD_ERR_NOT_FOUND = -2,    /* unknown parameter name          (Python: KeyError)                  */
+    DD_ERR_STATE = -3,        /* call order (e.g. forward before finalize)                          */
+    DD_ERR_HIP = -4,          /* a HIP runtime call failed                                           */
+    DD_ERR_NOMEM = -5,
+    DD_ERR_UNSUPPORTED = -6   /* config outside what the kernels implement                          */
+} dd_status;
+
+/* U-ViT hyper-parameters: the YAML model_params block (reference configs/uvit_*.yaml,
+ * constructor models/uvit.py:229-247). */
+typedef struct dd_config {
+    int32_t img_size;
+    int32_t patch_size;
+    int32_t in_chans;
+    int32_t embed_dim;
+    int32_t depth;
+    int32_t num_heads;
+    int32_t mlp_ratio;
+    int32_t num_classes;          /* <= 0: unconditional */
+    int32_t normalize_timesteps;  /* models/uvit.py:352-353 */
+    int32_t max_batch;            /* activation workspace is sized for this many images */
+} dd_config;
+
+/* arithmetic mode of the GEMM / attention operands (accumulation, residual stream,
+ * LayerNorm, softmax, head and DDPM update are fp32 in both) */
+enum { DD_PREC_BF16 = 0, DD_PREC_FP32 = 1 };
+
+/* sigma_t^2: beta-tilde as sampler.py:50, or beta as ddpm_core.py:57,72-75 (default there) */
+enum { DD_VAR_BETA_TILDE = 0, DD_VAR_BETA = 1 };
+
+/* where z ~ N(0, I) of the update comes from */
+enum { DD_NOISE_NONE = 0, DD_NOISE_BUFFER = 1, DD_NOISE_PHILOX = 2 };
+
+/* ---- context ---------------------------------------------------------------------- */
+int dd_abi_version(void);
+int dd_ctx_create(int device, dd_ctx** out);
+void dd_ctx_destroy(dd_ctx* ctx);
+const char* dd_last_error(dd_ctx* ctx);            /* valid until the next call on ctx */
+int dd_sync(dd_ctx* ctx, void* stream);
+
+/* The five fp32[1000] schedule tables as the engine computes them (must be bit-equal to
+ * sampler.py:40-44) plus the three per-step coefficients.  which: 0 betas, 1 alphas,
+ * 2 alphas_bar, 3 alphas_bar_previous, 4 betas_tilde (sampler.py order),
+ * 5 betas_tilde (ddpm_core.py:68-70 order), 6 c1=sqrt(1/alpha), 7 c2=(1-alpha)/sqrt(1-abar),
+ * 8 sigma=sqrt(betas_tilde).  Works without a GPU (host arithmetic only). */
+int dd_schedule_table(int which, float* out1000);
+
+/* ---- model: replaces UViT(**model_params) + load_state_dict (sampler.py:271-293) ---- */
+int dd_model_create(dd_ctx* ctx, const dd_config* cfg, dd_model** out);
+/* name = the reference state_dict key (models/uvit.py:228-336), data = host fp32,
+ * shape must match the reference's exactly.  Copies; may be called in any order. */
+int dd_model_set_param(dd_model* m, const char* name, const float* host_data,
+                       const int64_t* shape, int ndim);
+/* all parameters present -> pack into kernel layouts on the device. */
+int dd_model_finalize(dd_model* m, int precision);
+int64_t dd_model_num_params(const dd_model* m);
+void dd_model_destroy(dd_model* m);
+
+/* ---- eps = model(x, t, y)  (models/uvit.py:351-383) --------------------------------- */
+/* x_dev [B,C,S,S] fp32; t = the timestep every row of time_tensor holds (sampler.py:130);
+ * t_dev: NULL, or the reference's time_tensor itself, [B] fp32 on the device, when rows differ
+ * (then t is ignored); y_dev [B] int64 labels or NULL (must be non-NULL iff num_classes > 0,
+ * quirk Q5); eps_dev [B,C,S,S] fp32 out. */
+int dd_forward(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const float* t_dev,
+               const int64_t* y_dev, float* eps_dev, int B, void* stream);
+
+/* ---- x = postprocessing(eps, x, t)  (sampler.py:47-56 == ddpm_core.py:190-193) ------ */
+/* n = number of elements.  z_dev may be NULL (treated as 0); it is ignored when t == 0. */
+int dd_ddpm_step(dd_ctx* ctx, const float* x_dev, const float* eps_dev, const float* z_dev,
+                 int t, int variance, float* x_out_dev, int64_t n, void* stream);
+
+/* ---- one fused sampling step: x <- step(x, model(x,t,y), t) in place ---------------- */
+/* noise_mode DD_NOISE_BUFFER: z_dev [B,C,S,S] supplies z (parity with the torch CPU stream);
+ * DD_NOISE_PHILOX: z is generated on the device from (seed, t, element);
+ * eps_out_dev (optional) also receives eps. */
+int dd_sample_step(dd_ctx* ctx, dd_model* m, float* x_dev, int t, const int64_t* y_dev,
+                   int noise_mode, const float* z_dev, uint64_t seed, int variance,
+                   float* eps_out_dev, int B, void* stream);
+
+/* ---- the whole loop: get_samples DDPM branch (sampler.py:128-139) ------------------- */
+typedef struct dd_sample_args {
+    dd_model* first;        /* model used from t = t_start                                    */
+    dd_model* late;         /* or NULL; takes over AFTER the step at t == 1000 - t_switch     */
+    int32_t t_switch;       /* <= 0: never switch (reference default: inf, quirk Q6)          */
+    int32_t t_start;        /* normally 999                                                   */
+    int32_t t_end;          /* normally 0 (inclusive)                                         */
+    int32_t variance;       /* DD_VAR_*                                                       */
+    int32_t noise_mode;     /* DD_NOISE_PHILOX or DD_NOISE_NONE (host noise: use dd_sample_step) */
+    int32_t use_graph;      /* 1: capture one hipGraph per backbone and replay it             */
+    uint64_t seed;
+    const int64_t* y_dev;   /* [B] or NULL                                                    */
+    float* x_dev;           /* in: x_T, out: x at t_end, [B,C,S,S] fp32                       */
+    int32_t B;
+    int32_t reserved;
+} dd_sample_args;
+int dd_sample(dd_ctx* ctx, const dd_sample_args* args, void* stream);
+
+/* ---- measurement support ------------------------------------------------------------ */
+/* Time `iters` back-to-back launches of the engine's dominant kernel (the fc1 GEMM of
+ * model m at batch B, fused bias+GELU epilogue) with hipEvents on `stream`.
+ * Returns average milliseconds per launch in *ms_out and the launch's algorithmic FLOPs. */
+int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
+                  float* ms_out, double* flops_out);
+/* Per-step timing of the last dd_sample call, measured with hipEvents on its stream:
+ * [0] total ms, [1] ms in first-model steps, [2] ms in late-model steps. */
+int dd_last_sample_timing(dd_ctx* ctx, float out3[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUODIFF_H */
