@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of 1000-step DDPM DuoDiff sampling, CelebA 64x64
+(uvit_celeba_3.yaml shallow for t=999..700 + uvit_celeba.yaml full for t=699..0, t_switch=300),
+batch 128 per GPU, bf16 MFMA operands, synthetic seeded weights and noise.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one sampling step (U-ViT forward + fused DDPM update) over the rank's batch.
+K = 1000 (default) is one complete sampling run and `value` is then measured, not extrapolated.
+For K < 1000 the K timed steps keep the 30 % shallow / 70 % full mix (switch after
+round(0.3 K) steps) and value = images / (T_K * 1000 / K).
+Every rank samples its own batch (seed + rank): weak scaling, no collective inside the loop;
+one RCCL all_gather of the finished images closes the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+from duodiff_amd.config import ModelParams, load_config  # noqa: E402
+from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--batch", type=int, default=128, help="images per GPU")
+    p.add_argument("--t_switch", type=int, default=300)
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_batch", type=int, default=16)
+    p.add_argument("--cpu_steps", type=int, default=30)
+    return p.parse_args()
+
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(mp_s, mp_f, sd_s, sd_f, batch, steps, t_switch):
+    """The oracle (CPU port of the reference path) on the host cores, on a bounded sample of the
+    same workload: `batch` images, `steps` sampling steps with the 30/70 shallow/full mix."""
+    import oracle
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    # torch-functional oracle: the same ATen CPU kernels the reference's nn.Modules dispatch to
+    m_s = oracle.UViTTorchOracle(mp_s.as_dict(), sd_s)
+    m_f = oracle.UViTTorchOracle(mp_f.as_dict(), sd_f)
+    n_shallow = max(1, round(steps * t_switch / 1000.0))
+    tables = oracle.sampler_schedule()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, mp_f.in_chans, mp_f.img_size, mp_f.img_size, generator=g).numpy()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t = 999 - i
+        model = m_s if i < n_shallow else m_f
+        eps = model(x, np.full((batch,), t, np.float32))
+        z = torch.randn(x.shape, generator=g).numpy()
+        x = oracle.ddpm_step(x, eps, z, t, tables)
+    dt = time.perf_counter() - t0
+    value = batch / (dt * 1000.0 / steps)
+    return {"value": value, "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": f"torch-CPU functional oracle (fp32, {cores} threads), {batch} images x {steps} steps ({n_shallow} shallow + {steps - n_shallow} full) "
+                      f"in {dt:.1f} s, scaled to 1000 steps"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from duodiff_amd import sampler
+    from duodiff_amd.engine import sample_loop
+    from duodiff_amd.uvit import UViT
+
+    mp_s = ModelParams.from_dict(load_config(REPO / "configs" / "uvit_celeba_3.yaml"))
+    mp_f = ModelParams.from_dict(load_config(REPO / "configs" / "uvit_celeba.yaml"))
+    sd_s, sd_f = synthetic_state_dict(mp_s, 1237), synthetic_state_dict(mp_f, 1236)
+    dev = f"cuda:{local_rank}"
+    shallow = UViT(**mp_s.as_dict(), precision=a.precision, max_batch=a.batch).load_state_dict(sd_s).to(dev)
+    full = UViT(**mp_f.as_dict(), precision=a.precision, max_batch=a.batch).load_state_dict(sd_f).to(dev)
+    es, ef = shallow.engine_model(a.batch), full.engine_model(a.batch)
+    ctx = es.ctx
+
+    B, K, W = a.batch, a.steps, a.warmup
+    log(f"models ready on {dev}; B={B} K={K} W={W}")
+    seed = 0 + rank
+    sampler.seed_everything(seed)
+    x_T = torch.randn(B, mp_f.in_chans, mp_f.img_size, mp_f.img_size).to(dev).contiguous()
+    stream = torch.cuda.Stream(device=dev)
+    use_graph = not a.no_graph
+    # K timed steps: t = 999 .. 1000-K, switch after round(t_switch * K / 1000) steps
+    k_switch = a.t_switch if K == 1000 else max(1, round(a.t_switch * K / 1000.0))
+    t_end = 1000 - K
+
+    def run(x, n_steps, t_sw, t_stop):
+        with torch.cuda.stream(stream):
+            sample_loop(ctx, es, ef, x, t_switch=t_sw, t_start=999, t_end=t_stop, seed=seed, noise="philox",
+                        use_graph=use_graph, stream=stream)
+
+    # warmup: W untimed steps touching both backbones (also captures the graphs)
+    x = x_T.clone()  # one persistent state buffer: the captured graphs bake its address in
+    if W > 0:
+        w_sw = max(1, W // 2)
+        run(x, W, w_sw, 1000 - W)
+        stream.synchronize()
+        x.copy_(x_T)
+        log("warmup done")
+    gathered = [torch.empty(B, mp_f.img_size, mp_f.img_size, mp_f.in_chans, device=dev) for _ in range(world)] if world > 1 else None
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(x, K, k_switch, t_end)
+    with torch.cuda.stream(stream):
+        imgs = ((x + 1) / 2).permute(0, 2, 3, 1).contiguous()   # reference sampler.py:145-146
+        if dist is not None:
+            dist.all_gather(gathered, imgs)                      # the single collective: final images
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_all = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    dt = float(t_all.item())
+    log(f"timed region done: {dt:.3f} s")
+    timing = ctx.last_sample_timing()
+    finite = bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        images = B * world
+        value = images / (dt * 1000.0 / K)
+        flop_img = 0.3 * mp_s.flops_per_image() * 1000 + 0.7 * mp_f.flops_per_image() * 1000
+        e2e_tflops = value * flop_img / 1e12 / world
+        # dominant kernel: fc1 GEMM + bias + GELU of the full model (2/3 of the block's Linear FLOPs
+        # are the MLP pair), timed live with hipEvents on the launch stream
+        with torch.cuda.stream(stream):
+            ms, fl = ef.bench_gemm(B, iters=50, stream=stream)
+        ach = fl / (ms * 1e-3) / 1e12
+        log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
+        out = {
+            "metric": "images/sec (whole node) DuoDiff 1000-step CelebA-64",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt * 1000.0 / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "CelebA 64x64 DuoDiff: uvit_celeba_3 (t=999..700) + uvit_celeba (t=699..0), "
+                                   "t_switch=300, 1000-step DDPM, batch 128/GPU, device Philox noise",
+                       "batch_per_gpu": B, "t_switch": a.t_switch, "hipgraph": use_graph,
+                       "timed_steps": K, "switch_after_steps": k_switch,
+                       "seconds_per_sample": (dt * 1000.0 / K) / images, "finite": finite,
+                       "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2]},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "gemm_kernel<bf16,EPI_BIAS_GELU> fc1 M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
+                         "ms_per_launch": ms, "flops_per_launch": fl,
+                         "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline ...")
+            out["cpu_baseline"] = cpu_baseline(mp_s, mp_f, sd_s, sd_f, a.cpu_batch, a.cpu_steps, a.t_switch)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -68,7 +69,7 @@ struct dd_model {
     char* wsarena = nullptr;   // activations
     std::vector<BlockW> blocks;  // in.., mid, out..
     const float *emb_wt = nullptr, *emb_b = nullptr, *pos = nullptr, *label = nullptr;
-    const float *norm_g = nullptr, *norm_b = nullptr, *wdt = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
+    const float *norm_g = nullptr, *norm_b = nullptr, *wdec = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
     float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
     std::vector<void*> skips;
     float* dec = nullptr;
@@ -246,8 +247,13 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
         }
     }
-    HeadArgs ha{m->x, m->norm_g, m->norm_b, m->wdt, m->bdec, m->dec, B, L, m->N, m->extras, D, m->pd, m->pdp};
-    DD_HIP(c, launch_head_decode(ha, s));
+    // output head (uvit.py:377-378): final LayerNorm in fp32 into scratch (the MLP hidden buffer is
+    // free here), then decoder_pred as an exact-fp32 MFMA GEMM in BOTH precision modes, so eps is
+    // never rounded to bf16.  dec holds all L tokens per image; the extras are skipped downstream.
+    float* hf = (float*)m->hid;
+    DD_HIP(c, launch_layernorm<float>(m->x, m->norm_g, m->norm_b, hf, M, D, s));
+    GemmArgs<float> g{hf, nullptr, m->wdec, m->bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
+    DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s));
     return DD_OK;
 }
 
@@ -274,7 +280,7 @@ int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int
     int rc = run_model(m, x_dev, nullptr, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, x_dev, z_dev, eps_out, x_dev, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, noise_mode, variance};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -453,17 +459,15 @@ int dd_model_finalize(dd_model* m, int precision) {
     pack_block("mid_block.", false);
     for (int i = 0; i < m->half_depth; ++i) pack_block("out_blocks." + std::to_string(i) + ".", true);
 
-    // patch-embed weight [D, pd] -> transposed [pd, D] ; decoder_pred [pd, D] -> transposed, padded [D, pdp]
-    std::vector<float> wt((size_t)m->pd * D), wdt((size_t)D * m->pdp, 0.f);
+    // patch-embed weight [D, pd] -> transposed [pd, D] (coalesced over D in the embed kernel)
+    std::vector<float> wt((size_t)m->pd * D);
     const std::vector<float>& pe = P("patch_embed.proj.weight");
     for (int d = 0; d < D; ++d) for (int k = 0; k < m->pd; ++k) wt[(size_t)k * D + d] = pe[(size_t)d * m->pd + k];
-    const std::vector<float>& dw = P("decoder_pred.weight");
-    for (int j = 0; j < m->pd; ++j) for (int d = 0; d < D; ++d) wdt[(size_t)d * m->pdp + j] = dw[(size_t)j * D + d];
     const size_t o_wt = put_f32(wt.data(), wt.size()), o_eb = put_f32(P("patch_embed.proj.bias").data(), D);
     const size_t o_pos = put_f32(P("pos_embed").data(), (size_t)L * D);
     const size_t o_lab = m->cfg.num_classes > 0 ? put_f32(P("label_emb.weight").data(), (size_t)m->cfg.num_classes * D) : 0;
     const size_t o_ng = put_f32(P("norm.weight").data(), D), o_nb = put_f32(P("norm.bias").data(), D);
-    const size_t o_wdt = put_f32(wdt.data(), wdt.size()), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
+    const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
     align();
@@ -479,7 +483,7 @@ int dd_model_finalize(dd_model* m, int precision) {
         m->blocks.push_back(w);
     }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
-    m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdt = F(o_wdt); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
+    m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdec = F(o_wdec); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
 
     // ---- activation workspace (HBM-resident for the life of the model)
     const size_t Mp = (size_t)m->Mp_max;
@@ -489,7 +493,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_hid = take(Mp * hid * es), o_xb = take(Mp * D * es);
     std::vector<size_t> o_sk;
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
-    const size_t o_dec = take((size_t)m->cfg.max_batch * m->N * m->pd * 4);
+    const size_t o_dec = take(Mp * m->pd * 4);
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
     m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
@@ -521,7 +525,7 @@ int dd_forward(dd_ctx* c, dd_model* m, const float* x_dev, float t, const float*
     rc = run_model(m, x_dev, t_dev, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, DD_NOISE_NONE, 0};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -653,6 +657,92 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_out = ms / (float)iters;
     if (flops_out) *flops_out = 2.0 * (double)M * (double)m->hidden * (double)D;
+    return DD_OK;
+}
+
+int dd_set_gemm_variant(dd_ctx* c, int variant) {
+    if (!c) return DD_ERR_INVALID;
+    if (variant < 0 || variant > 8) return fail(c, DD_ERR_INVALID, "unknown GEMM variant");
+    set_gemm_variant(variant);
+    return DD_OK;
+}
+
+int dd_dev_gemm(dd_ctx* c, int M, int N, int K, int variant, int epilogue, int iters, int check, void* stream,
+                float* ms_out, long long* mismatch_out) {
+    if (!c || !ms_out || M < 1 || N < 1 || K < 64 || K % 64 || iters < 1) return DD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t Mp = (size_t)round_up(M, 256);
+    bf16_t *A = nullptr, *W = nullptr, *out0 = nullptr, *out1 = nullptr;
+    float *bias = nullptr, *x0 = nullptr, *x1 = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)A, (void*)W, (void*)out0, (void*)out1, (void*)bias, (void*)x0, (void*)x1})
+            if (p) (void)hipFree(p);
+    };
+#define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
+    DD_TRY(hipMalloc((void**)&A, Mp * K * 2));
+    DD_TRY(hipMalloc((void**)&W, (size_t)N * K * 2));
+    DD_TRY(hipMalloc((void**)&out0, Mp * N * 2));
+    DD_TRY(hipMalloc((void**)&out1, Mp * N * 2));
+    DD_TRY(hipMalloc((void**)&bias, (size_t)N * 4));
+    DD_TRY(hipMalloc((void**)&x0, Mp * N * 4));
+    DD_TRY(hipMalloc((void**)&x1, Mp * N * 4));
+    DD_TRY(launch_fill_random<bf16_t>(A, (long long)Mp * K, 1u, 1.0f, s));
+    DD_TRY(launch_fill_random<bf16_t>(W, (long long)N * K, 2u, 0.05f, s));
+    DD_TRY(launch_fill_random<float>(bias, N, 3u, 0.1f, s));
+    auto run = [&](int var, bf16_t* out, float* x) -> hipError_t {
+        GemmArgs<bf16_t> g{A, nullptr, W, bias, x, out, M, N, K, K, K, 0, N, var == variant ? (variant >> 8) : 0};
+        return launch_gemm_variant<bf16_t>(g, epilogue, var & 0xff, s);
+    };
+    long long mism = -1;
+    if (check) {
+        DD_TRY(launch_fill_random<float>(x0, (long long)Mp * N, 4u, 1.0f, s));
+        DD_TRY(launch_fill_random<float>(x1, (long long)Mp * N, 4u, 1.0f, s));
+        DD_TRY(hipMemsetAsync(out0, 0, Mp * N * 2, s));
+        DD_TRY(hipMemsetAsync(out1, 0, Mp * N * 2, s));
+        DD_TRY(run(0, out0, x0));
+        DD_TRY(run(variant, out1, x1));
+        DD_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned short> h0((size_t)M * N), h1((size_t)M * N);
+        std::vector<float> f0, f1;
+        mism = 0;
+        if (epilogue != EPI_BIAS_SET) {
+            DD_TRY(hipMemcpy(h0.data(), out0, h0.size() * 2, hipMemcpyDeviceToHost));
+            DD_TRY(hipMemcpy(h1.data(), out1, h1.size() * 2, hipMemcpyDeviceToHost));
+            long long rb[8] = {0}, cb[8] = {0}, tb[8] = {0};
+            for (size_t i = 0; i < h0.size(); ++i) {
+                if (h0[i] != h1[i]) {
+                    ++mism;
+                    const size_t r = i / N, cc = i % N;
+                    ++rb[(r % 128) / 16]; ++cb[(cc % 128) / 16]; ++tb[((r / 128) * ((N + 127) / 128) + cc / 128) % 8];
+                }
+            }
+            if (mism && getenv("DD_DEBUG"))
+                fprintf(stderr, "mismatch rows/16 in tile: %lld %lld %lld %lld %lld %lld %lld %lld | cols/16: %lld %lld %lld %lld %lld %lld %lld %lld | tile%%8: %lld %lld %lld %lld %lld %lld %lld %lld\n",
+                        rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], rb[6], rb[7], cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], cb[6], cb[7],
+                        tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], tb[6], tb[7]);
+        }
+        if (epilogue >= EPI_BIAS_RESID) {
+            f0.resize((size_t)M * N); f1.resize((size_t)M * N);
+            DD_TRY(hipMemcpy(f0.data(), x0, f0.size() * 4, hipMemcpyDeviceToHost));
+            DD_TRY(hipMemcpy(f1.data(), x1, f1.size() * 4, hipMemcpyDeviceToHost));
+            mism += std::memcmp(f0.data(), f1.data(), f0.size() * 4) != 0 ? 1 : 0;
+        }
+    }
+    DD_TRY(run(variant, out1, x1));  // warm
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    DD_TRY(hipEventCreate(&e0));
+    DD_TRY(hipEventCreate(&e1));
+    DD_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) DD_TRY(run(variant, out1, x1));
+    DD_TRY(hipEventRecord(e1, s));
+    DD_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DD_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#undef DD_TRY
+    cleanup();
+    *ms_out = ms / (float)iters;
+    if (mismatch_out) *mismatch_out = mism;
     return DD_OK;
 }
 

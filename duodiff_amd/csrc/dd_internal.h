@@ -63,9 +63,13 @@ struct GemmArgs {
     T* out;            // [Mp, ldo] or null
     int M, N, K, K1;
     int lda, lda2, ldo;
+    int ablate;        // development only: 1 skip epilogue memory traffic, 2 skip LDS-DMA after tile 0, 4 skip MFMA
 };
 
 template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s);
+template <typename T> hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s);
+void set_gemm_variant(int v);
+int get_gemm_variant();
 
 struct EmbedArgs {
     const float* x_img;      // [B,C,S,S]
@@ -88,19 +92,8 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
 
-struct HeadArgs {
-    const float* x_tok;   // [Mp, D]
-    const float* gamma;   // final norm
-    const float* beta;
-    const float* wdt;     // [D, pdp] decoder_pred weight transposed, pd padded to pdp
-    const float* bdec;    // [pd]
-    float* dec;           // [B*N, pd]
-    int B, L, N, extras, D, pd, pdp;
-};
-hipError_t launch_head_decode(const HeadArgs& a, hipStream_t s);
-
 struct FinalArgs {
-    const float* dec;      // [B*N, pd]
+    const float* dec;      // [B*L, pd] decoder_pred output for every token (extras included)
     const float* wconv;    // [C, C, 3, 3]
     const float* bconv;    // [C]
     const float* x_in;     // [B,C,S,S] or null (forward only)
@@ -109,12 +102,13 @@ struct FinalArgs {
     float* x_out;          // or null (may alias x_in)
     const StepState* st;
     const StepCoef* coef;  // [1000]
-    int B, C, S, P, noise_mode, variance;
+    int B, C, S, P, L, extras, noise_mode, variance;
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 
 hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, float* out,
                             StepCoef c, int use_noise, long long n, hipStream_t s);
+template <typename T> hipError_t launch_fill_random(T* p, long long n, unsigned seed, float scale, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
 hipError_t launch_advance_state(StepState* st, hipStream_t s);

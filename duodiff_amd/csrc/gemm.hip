@@ -17,6 +17,8 @@
 // 155-168, 203-208.
 #include "dd_internal.h"
 
+#include <type_traits>
+
 namespace dd {
 
 namespace {
@@ -28,8 +30,27 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
+// exact-erf GELU (nn.GELU default).  fp32 parity mode: libm erff.  bf16 mode: the output is
+// rounded to bf16 (2^-9 relative) anyway, so erf comes from Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute) on v_rcp/v_exp: ~14 VALU ops instead of erff's ~45, which made
+// the fc1 epilogue, not the MFMA loop, the bound of that kernel.
+template <typename T>
 __device__ __forceinline__ float gelu_erf(float v) {
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if constexpr (sizeof(T) == 4) {
+        return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    } else {
+        const float x = fabsf(v) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+        float p = fmaf(1.061405429f, t, -1.453152027f);
+        p = fmaf(p, t, 1.421413741f);
+        p = fmaf(p, t, -0.284496736f);
+        p = fmaf(p, t, 0.254829592f);
+        p *= t;
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+        const float erf_abs = fmaf(-p, e, 1.0f);          // erf(|v|/sqrt2) in [0, 1]
+        const float erf_v = copysignf(erf_abs, v);
+        return 0.5f * v * (1.0f + erf_v);
+    }
 }
 
 // Stage ROWS x 128 B into a lane-linear LDS tile with the source-side chunk swizzle.
@@ -66,25 +87,44 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const f32x4& a, co
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
 // BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as TM x TN MFMA 32x32 tiles.
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+// STAGES == 2: double buffer, one __syncthreads() per k-tile (drains the LDS-DMA each step).
+// STAGES >= 3: LDS ring; the LDS-DMA of the next STAGES-2 k-tiles stays in flight ACROSS the
+//   barrier: counted s_waitcnt vmcnt(N) + raw s_barrier, never __syncthreads() (it would emit
+//   vmcnt(0)).  Order per k-tile: every wave waits for ITS pieces of tile t, barrier (now all
+//   pieces of t have landed and everyone has finished reading tile t-1), re-stage the buffer of
+//   tile t-1 with tile t+STAGES-1, then read tile t.
+// XCD: blockIdx -> tile remap so that the blocks sharing an XCD (ids equal mod 8) get a contiguous
+//   run of tiles, i.e. the column tiles that re-read one A row-slab hit the same L2 (speed only).
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64)
 gemm_kernel(const GemmArgs<T> a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KT_ELEMS = 128 / (int)sizeof(T);  // k elements per k-tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // buffer b: A tile at b*STAGE_BYTES, then the W tile
+    constexpr int G = (BM + BN) / 8 / NW;           // LDS-DMA wave-instructions per k-tile per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / WN, wc = wave % WN;
     const int h = lane >> 5, r32 = lane & 31;
 
-    // tile mapping: consecutive blocks walk N first so that co-running blocks share A rows in L2
+    // XCD-aware, bijective block -> tile map; tiles walk N fastest so neighbours share the A slab
     const int n_tiles = (a.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int tile_m = wg / n_tiles, tile_n = wg % n_tiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int n_limit = a.N - n0;  // rows of W valid in this tile (>= 1)
 
@@ -97,6 +137,7 @@ gemm_kernel(const GemmArgs<T> a) {
     const long long sw = (long long)a.K * sizeof(T);
 
     auto stage = [&](int kt, int buf) {
+        if ((a.ablate & 2) && kt > 0) return;
         char* at = smem + buf * STAGE_BYTES;
         if (kt < nk1) stage_tile<BM, NW>(A1 + (long long)kt * 128, sa1, at, wave, lane, BM);
         else stage_tile<BM, NW>(A2 + (long long)(kt - nk1) * 128, sa2, at, wave, lane, BM);
@@ -111,14 +152,10 @@ gemm_kernel(const GemmArgs<T> a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    stage(0, 0);
-    __syncthreads();  // (emits vmcnt(0) for the LDS-DMA in flight)
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const char* Ab = smem + cur * STAGE_BYTES + (wr * (BM / WM)) * 128;
-        const char* Bb = smem + cur * STAGE_BYTES + A_BYTES + (wc * (BN / WN)) * 128;
+    auto compute = [&](int buf) {
+        if (a.ablate & 4) return;
+        const char* Ab = smem + buf * STAGE_BYTES + (wr * (BM / WM)) * 128;
+        const char* Bb = smem + buf * STAGE_BYTES + A_BYTES + (wc * (BN / WN)) * 128;
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             // logical 16-byte chunk this lane feeds: bf16 -> k = 16*step + 8h.. ; fp32 -> k = 16h + 4*step..
@@ -139,50 +176,340 @@ gemm_kernel(const GemmArgs<T> a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], af[i], bfr[j]);
+                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], bfr[j], af[i]);  // A-operand = W rows
         }
-        __syncthreads();
+    };
+
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
+        __syncthreads();  // (emits vmcnt(0) for the LDS-DMA in flight)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) stage(s, s);
+        int rd = 0, wrb = STAGES - 1;  // ring slots: read slot of tile kt, write slot of tile kt+STAGES-1
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = nk - 1 - kt;  // tiles issued after kt that may stay in flight (capped)
+            if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * G>();
+            else if (ahead >= 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, wrb);
+            compute(rd);
+            rd = rd + 1 == STAGES ? 0 : rd + 1;
+            wrb = wrb + 1 == STAGES ? 0 : wrb + 1;
+        }
     }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wc * (BN / WN) + j * 32 + r32;
-        const bool col_ok = col < a.N;
-        float bias = 0.f;
-        if (EPI != EPI_STORE && col_ok && a.bias) bias = a.bias[col];
+    // ---- epilogue.  The MFMA ran as D[n][m] = sum_k W[n][k] X[m][k] (weights as the A operand), so
+    // in the 32x32 C/D map the LANE is the output row m (lane&31) and the 16 REGISTERS are output
+    // columns n = (e&3) + 8*(e>>2) + 4*(lane>>5): each register quad is 4 consecutive columns of
+    // one row -> one 8-byte (bf16) or 16-byte (fp32) access per quad instead of four scalar ones.
+    // The T-typed output (bf16) additionally goes through a wave-private LDS strip, 32 rows at a
+    // time, so that it leaves the CU as whole 16-byte-per-lane row segments (CW*2 contiguous bytes
+    // per row) instead of 8-byte pieces scattered over 32 rows per instruction.
+    constexpr int CW = BN / WN;                         // columns owned by one wave
+    constexpr int STRIP_STRIDE = CW * (int)sizeof(T) + 16;  // padded row of the strip (16-B aligned)
+    constexpr int LPR = CW * (int)sizeof(T) / 16;       // lanes per strip row on the way out
+    constexpr int RPI = 64 / LPR;                       // rows per store instruction
+    char* strip = smem + wave * (32 * STRIP_STRIDE);
+    const bool use_out = EPI != EPI_BIAS_SET && a.out != nullptr;
+    if (use_out) __syncthreads();                       // every wave is done with the operand tiles
+
+    auto epilogue = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wr * (BM / WM) + i * 32 + r32;
+            const bool row_ok = !GUARD || row < a.M;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wr * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (!col_ok || row >= a.M) continue;
-                float v = acc[i][j][e];
-                if (EPI == EPI_STORE) {
-                    a.out[(long long)row * a.ldo + col] = Elem<T>::from_f32(v);
-                } else if (EPI == EPI_BIAS_GELU) {
-                    a.out[(long long)row * a.ldo + col] = Elem<T>::from_f32(gelu_erf(v + bias));
-                } else if (EPI == EPI_BIAS_RESID) {
-                    float* xp = a.xres + (long long)row * a.N + col;
-                    v = *xp + (v + bias);
-                    *xp = v;
-                    if (a.out) a.out[(long long)row * a.ldo + col] = Elem<T>::from_f32(v);
-                } else {  // EPI_BIAS_SET
-                    a.xres[(long long)row * a.N + col] = v + bias;
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cw = j * 32 + 8 * g + 4 * h;      // column within the wave's span
+                    const int col = n0 + wc * CW + cw;
+                    const bool ok = !GUARD || (row_ok && col < a.N);
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (ok) {
+                        if (EPI != EPI_STORE && a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf<T>(v[e]);
+                        }
+                        if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
+                            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * a.N + col);
+                            if (EPI == EPI_BIAS_RESID) v = *xp + v;
+                            *xp = v;
+                        }
+                    }
+                    if (use_out) {
+                        char* sp = strip + r32 * STRIP_STRIDE + cw * (int)sizeof(T);
+                        if constexpr (sizeof(T) == 2) {
+                            bf16_t o4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[e] = f2bf(v[e]);
+                            *reinterpret_cast<uint2*>(sp) = *reinterpret_cast<const uint2*>(o4);
+                        } else {
+                            *reinterpret_cast<f32x4*>(sp) = v;
+                        }
+                    }
+                }
+            }
+            if (use_out) {
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int sr = it * RPI + lane / LPR, sc = lane % LPR;   // strip row, 16-byte chunk
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(strip + sr * STRIP_STRIDE + sc * 16);
+                    const int orow = m0 + wr * (BM / WM) + i * 32 + sr;
+                    const int ocol = n0 + wc * CW + sc * (16 / (int)sizeof(T));
+                    if (!GUARD || (orow < a.M && ocol < a.N))
+                        *reinterpret_cast<f32x4*>(a.out + (long long)orow * a.ldo + ocol) = q;
                 }
             }
         }
+    };
+    if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) return;
+    // interior tiles (block-uniform test) skip every per-element bound check
+    if (m0 + BM <= a.M && n0 + BN <= a.N) epilogue(std::false_type{});
+    else epilogue(std::true_type{});
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent 256x256 kernel (bf16): the production path for the big Linears.
+//
+// Why this shape: an ablation of the 128x128 kernel on MI355X showed global->LDS delivery tops
+// out near 52 B/clk/CU, while a 128x128 tile needs 64 B/clk at full MFMA rate; 256x256 needs 32.
+// Why persistent: K is only 512..2048 (8..32 k-tiles per tile), so per-tile prologue/epilogue is
+// a large fraction; here the k-tile stream is continuous ACROSS tile boundaries -- while a tile's
+// epilogue runs, the LDS-DMA of the next tile's first k-tile is already in flight and the
+// epilogue's global stores stay in flight behind a counted vmcnt.
+// Why the row partition: M = B*(256+extras) is never a multiple of 256 (257 tiles of 128 rows on
+// 256 CUs is the worst quantisation there is).  Rows are independent, so each tile takes 256
+// contiguous "main" rows plus `e` (<= 8) rows of the tail region [256*q, M): tile counts become
+// q * N/256 -- for B = 128: 256 / 768 / 1024 tiles, exact multiples of the 256 CUs.  The tail rows
+// ride along as one extra 32-row MFMA tile per wave (+12.5 % MFMA issue, no extra weight traffic).
+//
+// 8 waves = 2 (M) x 4 (N); wave tile 128 x 64 (4 x 2 MFMA 32x32x16 tiles) + 1 tail tile.
+// LDS: 2 stages x (264 A rows + 256 W rows) x 128 B = 130 KB, + 8 wave-private 16-row strips for
+// the bf16 output transpose (inline-asm DS ops: hipcc would otherwise wait vmcnt(0) before every
+// strip write and may sink the strip reads into the exec-masked write branch).
+// ------------------------------------------------------------------------------------------
+struct Part256 {  // host-computed row partition
+    int q;          // main M-tiles (256 rows each)
+    int e;          // tail rows per tile (0..8)
+    int tail_base;  // = 256 * q
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void asm_ds_write_b64(unsigned addr, uint2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 asm_ds_read_b128_wait(unsigned addr) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
+constexpr int k256ARows = 264;                                   // 256 main + 8 tail rows
+constexpr int k256Stage = (k256ARows + 256) * 128;               // 66560 B
+constexpr int k256StripStride = 64 * 2 + 16;                     // 16-row strip of 64 bf16 columns
+constexpr int k256Lds = 2 * k256Stage + 8 * 16 * k256StripStride;  // 151552 B
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
+    typedef bf16_t T;
+    constexpr int TM = 4, TN = 2, NW = 8;
+    constexpr int A_BYTES = k256ARows * 128;
+    constexpr int N_EPI_STORES = (EPI == EPI_STORE || EPI == EPI_BIAS_GELU) ? TM * 4 : TM * TN * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, r32 = lane & 31;
+    const unsigned strip = lds_addr(smem + 2 * k256Stage + wave * (16 * k256StripStride));
+
+    const int n_tiles = a.N >> 8;
+    const int total = part.q * n_tiles;
+    const int G = gridDim.x, gx = G >> 3, xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;  // G % 8 == 0
+    auto tile_of = [&](int i) { return (i * 8 + xcd) * gx + wx; };
+    int n_my = 0;
+    while (tile_of(n_my) < total) ++n_my;
+    if (n_my == 0) return;
+
+    const int nk = a.K >> 6, nk1 = a.K1 >> 6;
+    const long long sa1 = (long long)a.lda * 2, sa2 = (long long)a.lda2 * 2, sw = (long long)a.K * 2;
+
+    auto stage = [&](int lin, int kt, int buf) {
+        if ((a.ablate & 2) && (kt > 0 || lin != tile_of(0))) return;
+        const int tm = lin / n_tiles, tn = lin - tm * n_tiles;
+        char* at = smem + buf * k256Stage;
+        const char* Ab;
+        long long sa;
+        if (kt < nk1) { Ab = reinterpret_cast<const char*>(a.A) + (long long)kt * 128; sa = sa1; }
+        else { Ab = reinterpret_cast<const char*>(a.A2) + (long long)(kt - nk1) * 128; sa = sa2; }
+        stage_tile<256, NW>(Ab + (long long)tm * 256 * sa, sa, at, wave, lane, 256);
+        if (wave == 0 && part.e > 0) {
+            // 8 tail rows of this tile -> LDS rows 256..263 (same source-side swizzle, row index 256 + r)
+            const int r = lane >> 3;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            long long row = (long long)part.tail_base + (long long)tm * part.e + (r < part.e ? r : part.e - 1);
+            row = row < a.M ? row : a.M - 1;
+            glds16(Ab + row * sa + c * 16, at + 256 * 128);
+        }
+        stage_tile<256, NW>(reinterpret_cast<const char*>(a.W) + (long long)tn * 256 * sw + (long long)kt * 128, sw,
+                            at + A_BYTES, wave, lane, 256);
+    };
+
+    f32x16 acc[TM][TN], accx;
+    auto compute = [&](int buf) {
+        if (a.ablate & 4) return;
+        const char* Ab = smem + buf * k256Stage;
+        const char* Bb = Ab + A_BYTES + (wc * 64) * 128;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int chunk = 2 * step + h;
+            f32x4 af[TM], bfr[TN], ax;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 32 + r32, tr = wc * 64 + r;
+                bfr[j] = lds_read16(Bb + r * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int tr = wr * 128 + i * 32 + r32;
+                af[i] = lds_read16(Ab + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));
+            }
+            {
+                const int tr = 256 + r32;  // rows >= 264 read the W tile's bytes: finite or not, they
+                ax = lds_read16(Ab + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));  // only reach dropped columns
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], bfr[j], af[i]);  // A-operand = W rows
+            mma_chunk<T>(accx, wr == 0 ? bfr[0] : bfr[1], ax);
+        }
+    };
+
+    // one register quad (4 consecutive output columns of one row) through the fused epilogue math
+    auto finish = [&](f32x4 q, long long row, int col) -> f32x4 {
+        if (EPI != EPI_STORE && a.bias) q += *reinterpret_cast<const f32x4*>(a.bias + col);
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = gelu_erf<T>(q[e]);
+        }
+        if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
+            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + row * a.N + col);
+            if (EPI == EPI_BIAS_RESID) q = *xp + q;
+            *xp = q;
+        }
+        return q;
+    };
+    auto pack4 = [](const f32x4& q) -> uint2 {
+        bf16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = f2bf(q[e]);
+        return *reinterpret_cast<const uint2*>(o4);
+    };
+
+    auto epilogue = [&](int lin) {
+        const int tm = lin / n_tiles, tn = lin - tm * n_tiles;
+        const bool use_out = EPI != EPI_BIAS_SET && a.out != nullptr;
+        const int col0 = tn * 256 + wc * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long row = (long long)tm * 256 + wr * 128 + i * 32 + r32;
+            f32x4 v[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    v[j][g] = finish(q, row, col0 + j * 32 + 8 * g + 4 * h);
+                }
+            if (use_out) {
+#pragma unroll
+                for (int half16 = 0; half16 < 2; ++half16) {
+                    if ((r32 >> 4) == half16) {
+                        const unsigned sp = strip + (r32 & 15) * k256StripStride + 8 * h;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) asm_ds_write_b64(sp + (j * 32 + 8 * g) * 2, pack4(v[j][g]));
+                    }
+                    // 16 rows x 128 B back out as 16-byte row segments: 8 lanes per row, 8 rows per instruction
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int sr = it * 8 + (lane >> 3), sc = lane & 7;
+                        const f32x4 q = asm_ds_read_b128_wait(strip + sr * k256StripStride + sc * 16);
+                        const long long orow = (long long)tm * 256 + wr * 128 + i * 32 + half16 * 16 + sr;
+                        *reinterpret_cast<f32x4*>(a.out + orow * a.ldo + col0 + sc * 8) = q;
+                    }
+                }
+            }
+        }
+        // tail rows: lane = tail row index (valid below part.e), registers = this wave's 32 columns
+        if (part.e > 0) {
+            const long long row = (long long)part.tail_base + (long long)tm * part.e + r32;
+            if (r32 < part.e && row < a.M) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = col0 + wr * 32 + 8 * g + 4 * h;
+                    f32x4 q = {accx[4 * g], accx[4 * g + 1], accx[4 * g + 2], accx[4 * g + 3]};
+                    q = finish(q, row, col);
+                    if (use_out) *reinterpret_cast<uint2*>(a.out + row * a.ldo + col) = pack4(q);
+                }
+            }
+        }
+    };
+
+    stage(tile_of(0), 0, 0);
+    int buf = 0;
+    bool stores_in_flight = false;
+    for (int i = 0; i < n_my; ++i) {
+        const int lin = tile_of(i);
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // the k-tile about to be read must have landed; only an epilogue's stores may be younger
+            if (kt == 0 && stores_in_flight) wait_vmcnt<N_EPI_STORES>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage(lin, kt + 1, buf ^ 1);
+            else if (i + 1 < n_my) stage(tile_of(i + 1), 0, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+        if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) { stores_in_flight = false; continue; }
+        epilogue(lin);
+        stores_in_flight = true;
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 hipError_t launch_cfg(const GemmArgs<T>& a, int epi, hipStream_t s) {
     const int m_tiles = (a.M + BM - 1) / BM, n_tiles = (a.N + BN - 1) / BN;
     const dim3 grid(m_tiles * n_tiles), block(WM * WN * 64);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
 #define DD_LAUNCH(E)                                                                              \
     {                                                                                             \
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, E>), grid, block, lds, s, a);          \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, STAGES, E>), grid, block, lds, s, a);  \
         return hipGetLastError();                                                                 \
     }
     switch (epi) {
@@ -195,36 +522,131 @@ hipError_t launch_cfg(const GemmArgs<T>& a, int epi, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 hipError_t init_cfg() {
-    const int lds = 2 * (BM + BN) * 128;
+    const int lds = STAGES * (BM + BN) * 128;
     hipError_t e = hipSuccess;
 #define DD_ATTR(E)                                                                                         \
     if (e == hipSuccess)                                                                                   \
-        e = hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, E>,                            \
+        e = hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, STAGES, E>,                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET)
 #undef DD_ATTR
     return e;
 }
 
+int g_variant_bf16 = 8;  // 8 = persistent 256x256 (falls back to 0 for shapes it does not take)
+int g_num_cus = 256;
+
+// Row partition for gemm256 (see the kernel's header): q main tiles, e tail rows per tile, chosen to
+// minimise rounds over the CUs; returns false when the shape does not fit the kernel.
+bool plan256(int M, int N, int K, int K1, Part256& p) {
+    if (N % 256 || K % 64 || K1 % 64 || M < 256) return false;
+    const int nt = N / 256;
+    const int q_hi = M / 256, q_lo = (M + 263) / 264;
+    double best = 1e30;
+    int best_q = -1;
+    for (int q = q_hi; q >= q_lo && q >= 1; --q) {
+        const int tail = M - 256 * q;
+        const int e = tail > 0 ? (tail + q - 1) / q : 0;
+        if (e > 8) continue;
+        const long long tiles = (long long)q * nt;
+        const double rounds = (double)((tiles + g_num_cus - 1) / g_num_cus);
+        const double cost = rounds * (e > 0 ? 1.125 : 1.0);
+        if (cost < best - 1e-9) { best = cost; best_q = q; }
+    }
+    if (best_q < 0) return false;
+    p.q = best_q;
+    const int tail = M - 256 * best_q;
+    p.e = tail > 0 ? (tail + best_q - 1) / best_q : 0;
+    p.tail_base = 256 * best_q;
+    return true;
+}
+
+hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipStream_t s) {
+    const int tiles = p.q * (a.N / 256);
+    int grid = g_num_cus;
+    if (tiles < grid) grid = (tiles + 7) / 8 * 8;   // multiple of 8 (XCD grouping)
+#define DD_LAUNCH(E)                                                                                  \
+    {                                                                                                 \
+        hipLaunchKernelGGL((gemm256_kernel<E>), dim3(grid), dim3(512), k256Lds, s, a, p);             \
+        return hipGetLastError();                                                                     \
+    }
+    switch (epi) {
+        case EPI_STORE: DD_LAUNCH(EPI_STORE)
+        case EPI_BIAS_GELU: DD_LAUNCH(EPI_BIAS_GELU)
+        case EPI_BIAS_RESID: DD_LAUNCH(EPI_BIAS_RESID)
+        case EPI_BIAS_SET: DD_LAUNCH(EPI_BIAS_SET)
+    }
+#undef DD_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+// tile/pipeline variants (bf16); the fp32 parity mode always uses variant 0
+#define DD_VARIANTS(X)          \
+    X(0, 128, 128, 2, 2, 2)     \
+    X(1, 256, 128, 4, 2, 2)     \
+    X(2, 256, 128, 4, 2, 3)     \
+    X(3, 256, 256, 2, 4, 2)     \
+    X(4, 128, 256, 2, 4, 3)     \
+    X(5, 256, 256, 4, 2, 2)     \
+    X(6, 128, 128, 2, 2, 3)     \
+    X(7, 128, 128, 2, 2, 4)
+
 }  // namespace
 
 // dynamic-LDS opt-in for every instantiation, once per process (kept out of the launch path so
 // that launches are capturable into a hipGraph)
 hipError_t init_gemm_kernels() {
-    hipError_t e = init_cfg<bf16_t, 128, 128, 2, 2>();
-    if (e == hipSuccess) e = init_cfg<float, 128, 128, 2, 2>();
+    hipError_t e = init_cfg<float, 128, 128, 2, 2, 2>();
+#define X(ID, BM, BN, WM, WN, ST) \
+    if (e == hipSuccess) e = init_cfg<bf16_t, BM, BN, WM, WN, ST>();
+    DD_VARIANTS(X)
+#undef X
+#define DD_ATTR(E)                                                                                  \
+    if (e == hipSuccess)                                                                            \
+        e = hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
+    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET)
+#undef DD_ATTR
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return e;
+}
+
+void set_gemm_variant(int v) { g_variant_bf16 = v; }
+int get_gemm_variant() { return g_variant_bf16; }
+
+template <typename T>
+hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s) {
+    constexpr int KT = 128 / (int)sizeof(T);
+    if (a.K % KT || a.K1 % KT || a.K1 > a.K || (a.K1 < a.K && !a.A2)) return hipErrorInvalidValue;
+    if constexpr (sizeof(T) == 4) {
+        return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
+    } else {
+        if (variant == 8) {
+            Part256 p;
+            if (plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, epilogue, p, s);
+            variant = 0;  // shapes the 256x256 kernel does not take (small N, tiny M)
+        }
+        switch (variant) {
+#define X(ID, BM, BN, WM, WN, ST) \
+    case ID: return launch_cfg<T, BM, BN, WM, WN, ST>(a, epilogue, s);
+            DD_VARIANTS(X)
+#undef X
+        }
+        return hipErrorInvalidValue;
+    }
 }
 
 template <typename T>
 hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s) {
-    constexpr int KT = 128 / (int)sizeof(T);
-    if (a.K % KT || a.K1 % KT || a.K1 > a.K || (a.K1 < a.K && !a.A2)) return hipErrorInvalidValue;
-    return launch_cfg<T, 128, 128, 2, 2>(a, epilogue, s);
+    return launch_gemm_variant<T>(a, epilogue, g_variant_bf16, s);
 }
 
+template hipError_t launch_gemm_variant<bf16_t>(const GemmArgs<bf16_t>&, int, int, hipStream_t);
+template hipError_t launch_gemm_variant<float>(const GemmArgs<float>&, int, int, hipStream_t);
 template hipError_t launch_gemm<bf16_t>(const GemmArgs<bf16_t>&, int, hipStream_t);
 template hipError_t launch_gemm<float>(const GemmArgs<float>&, int, hipStream_t);
 

@@ -156,64 +156,6 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Output head, part 1: final LayerNorm + decoder_pred (D -> P*P*C) on the patch tokens only
-// (reference models/uvit.py:377-380).  32 tokens per workgroup: the normalised rows are parked
-// in LDS (stride D+1: conflict-free column walks), then thread (token, output group) does the
-// short dot products against the transposed weight.
-// ------------------------------------------------------------------------------------------
-constexpr int kHeadTok = 32;
-
-__global__ void __launch_bounds__(256) head_decode_kernel(const HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* rows = reinterpret_cast<float*>(smem_raw);  // [32][D+1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ld = a.D + 1;
-    const long long tok0 = (long long)blockIdx.x * kHeadTok;
-    const long long ntok = (long long)a.B * a.N;
-
-    for (int j = wave; j < kHeadTok; j += 4) {
-        const long long tk = tok0 + j;
-        if (tk >= ntok) {
-            for (int d = lane; d < a.D; d += 64) rows[j * ld + d] = 0.f;
-            continue;
-        }
-        const long long row = (tk / a.N) * a.L + a.extras + (tk % a.N);
-        const float* xr = a.x_tok + row * a.D;
-        float s = 0.f;
-        for (int d = lane; d < a.D; d += 64) s += xr[d];
-        const float mean = wave_sum(s) / (float)a.D;
-        float q2 = 0.f;
-        for (int d = lane; d < a.D; d += 64) { const float dl = xr[d] - mean; q2 += dl * dl; }
-        const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)a.D + 1e-5f);
-        for (int d = lane; d < a.D; d += 64) rows[j * ld + d] = (xr[d] - mean) * rstd * a.gamma[d] + a.beta[d];
-    }
-    __syncthreads();
-
-    // thread -> (token = tid & 31, group = tid >> 5 of 8); group owns outputs [group*U, group*U + U)
-    const int token = tid & 31, grp = tid >> 5;
-    const int U = a.pdp / 8;  // pdp = pd rounded up to a multiple of 8, U <= 8
-    float acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    const float* rr = rows + token * ld;
-    for (int k = 0; k < a.D; ++k) {
-        const float xv = rr[k];
-        const float* w = a.wdt + (long long)k * a.pdp + grp * U;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (u < U) acc[u] = fmaf(xv, w[u], acc[u]);
-    }
-    const long long tk = tok0 + token;
-    if (tk < ntok) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = grp * U + u;
-            if (u < U && j < a.pd) a.dec[tk * a.pd + j] = acc[u] + a.bdec[j];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Device noise: Philox4x32-10 counter RNG + Box-Muller.  Counter = (element/4, t, 0, 0),
 // key = seed.  Statistically N(0,1); NOT the torch CPU mt19937 stream (that is DD_NOISE_BUFFER).
 // ------------------------------------------------------------------------------------------
@@ -243,12 +185,13 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 }
 
 // ------------------------------------------------------------------------------------------
-// Output head, part 2 + DDPM update: unpatchify ("B (h w) (p1 p2 C) -> B C (h p1) (w p2)",
+// Output head (after final LayerNorm + decoder_pred GEMM) + DDPM update: unpatchify ("B (h w) (p1 p2 C) -> B C (h p1) (w p2)",
 // reference models/uvit.py:125-132), 3x3 conv pad 1 (:382), then
 //   x <- sqrt(1/a_t) (x - (1-a_t)/sqrt(1-abar_t) eps) + sigma_t z      (sampler.py:47-56)
 // One thread per pixel, all output channels; eps never goes to HBM unless asked for.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
+#pragma clang fp contract(off)  // the update must round like the reference: mul, sub, mul, add -- no FMA
     const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
     const int S = a.S, P = a.P, C = a.C;
     const long long npix = (long long)a.B * S * S;
@@ -267,7 +210,7 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
         for (int dx = 0; dx < 3; ++dx) {
             const int xx = x + dx - 1;
             if (xx < 0 || xx >= S) continue;
-            const long long tok = (long long)b * g * g + (yy / P) * g + (xx / P);
+            const long long tok = (long long)b * a.L + a.extras + (yy / P) * g + (xx / P);
             const float* u = a.dec + tok * pd + ((yy % P) * P + (xx % P)) * C;
             for (int ci = 0; ci < C; ++ci) {
                 const float uv = u[ci];
@@ -287,10 +230,10 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
         if (a.eps_out) a.eps_out[e] = eps;
         if (a.x_out) {
             // same operation order and roundings as the reference (no FMA contraction)
-            float v = __fmul_rn(cf.c1, __fsub_rn(a.x_in[e], __fmul_rn(cf.c2, eps)));
+            float v = cf.c1 * (a.x_in[e] - cf.c2 * eps);
             if (t > 0) {
-                if (a.noise_mode == 1) v = __fadd_rn(v, __fmul_rn(sigma, a.z[e]));
-                else if (a.noise_mode == 2) v = __fadd_rn(v, __fmul_rn(sigma, philox_normal(a.st->seed, (unsigned long long)e, t)));
+                if (a.noise_mode == 1) v = v + sigma * a.z[e];
+                else if (a.noise_mode == 2) v = v + sigma * philox_normal(a.st->seed, (unsigned long long)e, t);
             }
             a.x_out[e] = v;
         }
@@ -300,10 +243,11 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                  const float* __restrict__ z, float* __restrict__ out, StepCoef c,
                                  int use_noise, int variance_beta, long long n) {
+#pragma clang fp contract(off)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float v = __fmul_rn(c.c1, __fsub_rn(x[i], __fmul_rn(c.c2, eps[i])));
-    if (use_noise) v = __fadd_rn(v, __fmul_rn(variance_beta ? c.sigma_beta : c.sigma_tilde, z[i]));
+    float v = c.c1 * (x[i] - c.c2 * eps[i]);
+    if (use_noise) v = v + (variance_beta ? c.sigma_beta : c.sigma_tilde) * z[i];
     out[i] = v;
 }
 
@@ -342,17 +286,26 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 template hipError_t launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
 template hipError_t launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 
-hipError_t launch_head_decode(const HeadArgs& a, hipStream_t s) {
-    const long long ntok = (long long)a.B * a.N;
-    const size_t lds = (size_t)kHeadTok * (a.D + 1) * sizeof(float);
-    hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)((ntok + kHeadTok - 1) / kHeadTok)), dim3(256), lds, s, a);
+hipError_t init_rowops_kernels() { return hipSuccess; }
+
+namespace {
+// deterministic pseudo-random fill for the GEMM development harness (uniform [-1, 1))
+template <typename T>
+__global__ void fill_random_kernel(T* p, long long n, unsigned seed, float scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    p[i] = Elem<T>::from_f32(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+}
+}  // namespace
+template <typename T>
+hipError_t launch_fill_random(T* p, long long n, unsigned seed, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(fill_random_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, seed, scale);
     return hipGetLastError();
 }
-
-hipError_t init_rowops_kernels() {
-    return hipFuncSetAttribute((const void*)head_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kHeadTok * (1024 + 1) * (int)sizeof(float));
-}
+template hipError_t launch_fill_random<bf16_t>(bf16_t*, long long, unsigned, float, hipStream_t);
+template hipError_t launch_fill_random<float>(float*, long long, unsigned, float, hipStream_t);
 
 hipError_t launch_final(const FinalArgs& a, hipStream_t s) {
     const long long npix = (long long)a.B * a.S * a.S;

@@ -141,6 +141,15 @@ int dd_sample(dd_ctx* ctx, const dd_sample_args* args, void* stream);
  * Returns average milliseconds per launch in *ms_out and the launch's algorithmic FLOPs. */
 int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
                   float* ms_out, double* flops_out);
+/* Development harness: one bf16 GEMM  C[M,N] = A[M,K] W[N,K]^T  on pseudo-random operands with
+ * tile/pipeline `variant` and fused `epilogue` (0 store, 1 bias+GELU, 2 bias+residual, 3 bias+set),
+ * `iters` timed launches (hipEvents on `stream`).  *mismatch_out = number of output elements that
+ * differ bitwise from variant 0 (all variants accumulate k in the same order), or -1 if check==0. */
+int dd_dev_gemm(dd_ctx* ctx, int M, int N, int K, int variant, int epilogue, int iters, int check,
+                void* stream, float* ms_out, long long* mismatch_out);
+/* Select the GEMM variant the engine uses for bf16 models (default 0). */
+int dd_set_gemm_variant(dd_ctx* ctx, int variant);
+
 /* Per-step timing of the last dd_sample call, measured with hipEvents on its stream:
  * [0] total ms, [1] ms in first-model steps, [2] ms in late-model steps. */
 int dd_last_sample_timing(dd_ctx* ctx, float out3[3]);

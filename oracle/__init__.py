@@ -27,4 +27,5 @@ from .uvit_oracle import (  # noqa: F401
     unpatchify,
     conv3x3,
 )
+from .uvit_oracle_torch import UViTTorchOracle  # noqa: F401
 from .sampling_oracle import get_samples, scheduler_sample, seed_everything  # noqa: F401

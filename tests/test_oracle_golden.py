@@ -128,3 +128,25 @@ def test_full_size_forward(golden, name):
     assert abs(eps.mean(dtype=np.float64) - st[0]) < 1e-5
     assert abs(eps.std(dtype=np.float64) - st[1]) < 1e-5
     assert abs(np.abs(eps.astype(np.float64)).sum() - float(fx["abs_checksum"])) < 1e-6 * eps.size * 50
+
+
+@pytest.mark.parametrize("name", ["uvit_celeba", "uvit_imagenet64_3", "uvit_imagenet256_3"])
+def test_torch_functional_oracle_full_size(golden, name):
+    """The torch-functional variant (bench.py's CPU baseline) is pinned by the same vectors."""
+    fx = golden(f"uvit_full_{name}.npz")
+    mp = ModelParams.from_dict(load_config(REPO / "configs" / f"{name}.yaml"))
+    m = oracle.UViTTorchOracle(mp.as_dict(), synthetic_state_dict(mp, int(fx["seed"])))
+    B = fx["x"].shape[0]
+    eps = m(fx["x"], np.full((B,), float(fx["t"]), np.float32), fx["y"] if fx["y"].size else None)
+    np.testing.assert_allclose(eps[:, :, :16, :16], fx["eps_slice"], rtol=0, atol=2e-5)
+    assert abs(eps.astype(np.float64).sum() - float(fx["checksum"])) < 1e-5 * eps.size
+
+
+@pytest.mark.parametrize("name", ["uncond_norm", "cond_raw"])
+def test_torch_functional_oracle_tiny(golden, name):
+    fx = golden(f"uvit_tiny_{name}.npz")
+    cfg = tiny_cfg_from_fixture(fx)
+    mp = ModelParams.from_dict(cfg)
+    m = oracle.UViTTorchOracle(cfg, synthetic_state_dict(mp, int(fx["seed"])))
+    eps = m(fx["x"], fx["t"], fx["y"] if "y" in fx.files else None)
+    np.testing.assert_allclose(eps, fx["eps"], rtol=0, atol=1e-5)
