@@ -34,7 +34,7 @@ template <> struct AttnLayout<float> {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1)
 attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, int H, int D) {
     using Lay = AttnLayout<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,27 +53,67 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     constexpr int CPR = kHD / EPC;                     // chunks per row (8 bf16 / 16 fp32)
 
     // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
-    for (int idx = tid; idx < nkt * 32 * CPR; idx += 256) {
-        const int key = idx / CPR, ch = idx % CPR;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (key < L) {
-            kv = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
-            vv = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
-        }
-        *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = kv;
-        T tmp[EPC];
-        *reinterpret_cast<f32x4*>(tmp) = vv;
+    if constexpr (sizeof(T) == 2) {
+        // two keys per item, so V^T goes in as dwords {V[2k][d], V[2k+1][d]} instead of 2-byte writes
+        const int items = nkt * 16 * CPR;
+        for (int idx = tid; idx < items; idx += 256) {
+            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
+            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+            if (key < L) {
+                k0 = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
+                v0 = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
+            }
+            if (key + 1 < L) {
+                k1 = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
+                v1 = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
+            }
+            *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0;
+            *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1;
+            const bf16x8 a = __builtin_bit_cast(bf16x8, v0), b = __builtin_bit_cast(bf16x8, v1);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-            *reinterpret_cast<T*>(Vt + (ch * EPC + e) * Lay::kRowV + key * (int)sizeof(T)) = tmp[e];
+            for (int e = 0; e < 8; ++e) {
+                const unsigned pair = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
+                *reinterpret_cast<unsigned*>(Vt + (ch * 8 + e) * Lay::kRowV + key * 2) = pair;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < nkt * 32 * CPR; idx += 256) {
+            const int key = idx / CPR, ch = idx % CPR;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < L) {
+                kv = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
+                vv = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
+            }
+            *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = kv;
+            T tmp[EPC];
+            *reinterpret_cast<f32x4*>(tmp) = vv;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                *reinterpret_cast<T*>(Vt + (ch * EPC + e) * Lay::kRowV + key * (int)sizeof(T)) = tmp[e];
+        }
     }
+
+    // Q fragments of a 32-query chunk, straight from HBM/L2 (rows >= L are clamped and dropped later)
+    constexpr int NQF = sizeof(T) == 2 ? 4 : 8;
+    auto load_q = [&](int qc, f32x4 (&qf)[NQF]) {
+        const int q = qc * 32 + r32;
+        const T* qrow = qbase + (long long)(q < L ? q : L - 1) * ld;
+#pragma unroll
+        for (int i = 0; i < NQF; ++i)
+            qf[i] = sizeof(T) == 2 ? *reinterpret_cast<const f32x4*>(qrow + 16 * i + 8 * half)
+                                   : *reinterpret_cast<const f32x4*>(qrow + 32 * half + 4 * i);
+    };
+    f32x4 qnext[NQF];
+    load_q(wave, qnext);   // in flight while the K/V tiles are being staged
     __syncthreads();
 
     const int nqc = (L + 31) / 32;
     for (int qc = wave; qc < nqc; qc += 4) {
         const int q = qc * 32 + r32;
-        const int qs = q < L ? q : L - 1;              // clamp: rows >= L are computed and dropped
-        const T* qrow = qbase + (long long)qs * ld;
+        f32x4 qcur[NQF];
+#pragma unroll
+        for (int i = 0; i < NQF; ++i) qcur[i] = qnext[i];
+        if (qc + 4 < nqc) load_q(qc + 4, qnext);       // next chunk's Q lands under this chunk's work
 
         // ---- S^T = K . Q^T, nkt tiles of 32 keys x 32 queries
         f32x16 s[kMaxKeyTiles];
@@ -85,8 +125,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         if constexpr (sizeof(T) == 2) {
             bf16x8 qf[4];
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
-                qf[st] = *reinterpret_cast<const bf16x8*>(qrow + 16 * st + 8 * half);
+            for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
                 if (t < nkt) {
@@ -102,8 +141,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
             f32x4 qf[8];
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-                qf[g] = *reinterpret_cast<const f32x4*>(qrow + 32 * half + 4 * g);
+            for (int g = 0; g < 8; ++g) qf[g] = qcur[g];
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
                 if (t < nkt) {
@@ -119,28 +157,36 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             }
         }
 
-        // ---- softmax over keys (registers x tiles in-lane, then the other lane-half)
+        // ---- softmax over keys (registers x tiles in-lane, then the other lane-half).
+        // softmax(s/8) = exp2((s - max s) * log2(e)/8) / sum: the 1/sqrt(64) scale rides in the exp2
+        // argument; only the last key tile can hold padded keys, so only it is masked.
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < kMaxKeyTiles; ++t) {
             if (t < nkt) {
+                if (t == nkt - 1) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    const float v = key < L ? s[t][e] * 0.125f : -INFINITY;   // 1/sqrt(64), exact
-                    s[t][e] = v;
-                    mx = fmaxf(mx, v);
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                        if (key >= L) s[t][e] = -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
+        const float mxs = mx * kScaleLog2e;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < kMaxKeyTiles; ++t) {
             if (t < nkt) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p = sizeof(T) == 2 ? __expf(s[t][e] - mx) : expf(s[t][e] - mx);
+                    float p;
+                    if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[t][e], kScaleLog2e, -mxs));
+                    else p = expf((s[t][e] - mx) * 0.125f);
                     s[t][e] = p;
                     sum += p;
                 }
