@@ -69,6 +69,36 @@ __device__ __forceinline__ void stage_tile(const char* g, long long row_stride, 
     }
 }
 
+// GELU on a register quad; written on whole vectors so that the FMA chain maps onto packed fp32
+// VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of math per issue slot).
+template <typename T>
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = gelu_erf<T>(v[e]);
+        return r;
+    } else {
+        const f32x4 ax = __builtin_elementwise_abs(v);
+        const f32x4 x = ax * 0.70710678118654752440f;
+        const f32x4 d = x * 0.3275911f + 1.0f;
+        f32x4 t, e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(d[i]);
+        f32x4 p = t * 1.061405429f + (-1.453152027f);
+        p = p * t + 1.421413741f;
+        p = p * t + (-0.284496736f);
+        p = p * t + 0.254829592f;
+        p = p * t;
+        const f32x4 a2 = x * x * (-1.4426950408889634f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a2[i]);
+        // 0.5 v (1 + erf(v/sqrt2)) with erf(|z|) = 1 - p e  ==>  gelu(v) = 0.5 (v + |v|) - 0.5 |v| p e
+        const f32x4 w = (ax * 0.5f) * (p * e);
+        return (v + ax) * 0.5f - w;
+    }
+}
+
 __device__ __forceinline__ f32x4 lds_read16(const char* p) {
     return *reinterpret_cast<const f32x4*>(p);
 }
@@ -238,10 +268,7 @@ gemm_kernel(const GemmArgs<T> a) {
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     if (ok) {
                         if (EPI != EPI_STORE && a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
-                        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf<T>(v[e]);
-                        }
+                        if (EPI == EPI_BIAS_GELU) v = gelu_erf4<T>(v);
                         if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
                             f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * a.N + col);
                             if (EPI == EPI_BIAS_RESID) v = *xp + v;
@@ -312,6 +339,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 __device__ __forceinline__ void asm_ds_write_b64(unsigned addr, uint2 v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+// four 16-byte LDS reads at addr + {0, 32, 64, 96} bytes, one wait
+__device__ __forceinline__ void asm_ds_read_4x_b128_wait(unsigned addr, f32x4 (&r)[4]) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+        "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(addr)
+        : "memory");
+}
 __device__ __forceinline__ f32x4 asm_ds_read_b128_wait(unsigned addr) {
     f32x4 r;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
@@ -321,7 +357,8 @@ __device__ __forceinline__ f32x4 asm_ds_read_b128_wait(unsigned addr) {
 constexpr int k256ARows = 264;                                   // 256 main + 8 tail rows
 constexpr int k256Stage = (k256ARows + 256) * 128;               // 66560 B
 constexpr int k256StripStride = 64 * 2 + 16;                     // 16-row strip of 64 bf16 columns
-constexpr int k256Lds = 2 * k256Stage + 8 * 16 * k256StripStride;  // 151552 B
+constexpr int k256BiasOff = 2 * k256Stage + 8 * 16 * k256StripStride;  // two 1 KB bias slots (tile parity)
+constexpr int k256Lds = k256BiasOff + 2 * 1024;                        // 153600 B
 
 template <int EPI>
 __global__ void __launch_bounds__(512)
@@ -349,94 +386,187 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     const int nk = a.K >> 6, nk1 = a.K1 >> 6;
     const long long sa1 = (long long)a.lda * 2, sa2 = (long long)a.lda2 * 2, sw = (long long)a.K * 2;
 
-    auto stage = [&](int lin, int kt, int buf) {
-        if ((a.ablate & 2) && (kt > 0 || lin != tile_of(0))) return;
-        const int tm = lin / n_tiles, tn = lin - tm * n_tiles;
+    // LDS-DMA addressing: wave-uniform 64-bit base (SGPRs) + ONE 32-bit per-lane offset per operand.
+    // Lane l of wave-instruction `inst` writes LDS row r = inst*8 + (l>>3), 16-byte slot l&7, and
+    // must therefore fetch logical chunk (l&7) ^ ((r>>1)&7).  With r = 8*inst + lr that is
+    // (l&7) ^ (lr>>1) for even inst and the same ^ 4 for odd inst, i.e. byte offset ^ 64: per-lane
+    // address state is two VGPRs for the whole kernel (it used to be ~18 and got spilled).
+    auto stage = [&](int tm, int tn, int kt, int buf, int parity, bool first) {
+        if ((a.ablate & 2) && !first) return;
+        // recomputed per call from an opaque copy of the lane id (4 VALU ops): kept live across the
+        // k-loop these offsets were the registers the allocator chose to spill
+        unsigned l = (unsigned)lane;
+        asm volatile("" : "+v"(l));
+        const unsigned lr = l >> 3;
+        const unsigned swz = ((l & 7u) ^ (lr >> 1)) << 4;
+        const unsigned voff_a = lr * (unsigned)sa1 + swz;
+        const unsigned voff_w = lr * (unsigned)sw + swz;
         char* at = smem + buf * k256Stage;
-        const char* Ab;
-        long long sa;
-        if (kt < nk1) { Ab = reinterpret_cast<const char*>(a.A) + (long long)kt * 128; sa = sa1; }
-        else { Ab = reinterpret_cast<const char*>(a.A2) + (long long)(kt - nk1) * 128; sa = sa2; }
-        stage_tile<256, NW>(Ab + (long long)tm * 256 * sa, sa, at, wave, lane, 256);
-        if (wave == 0 && part.e > 0) {
-            // 8 tail rows of this tile -> LDS rows 256..263 (same source-side swizzle, row index 256 + r)
-            const int r = lane >> 3;
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            long long row = (long long)part.tail_base + (long long)tm * part.e + (r < part.e ? r : part.e - 1);
-            row = row < a.M ? row : a.M - 1;
-            glds16(Ab + row * sa + c * 16, at + 256 * 128);
+        if (kt == 0 && wave == 1 && EPI != EPI_STORE && a.bias)   // this tile's 256 bias values -> LDS
+            glds16(a.bias + tn * 256 + lane * 4, at - buf * k256Stage + k256BiasOff + parity * 1024);
+        const char* Ab = kt < nk1 ? reinterpret_cast<const char*>(a.A) + (long long)kt * 128
+                                  : reinterpret_cast<const char*>(a.A2) + (long long)(kt - nk1) * 128;
+        const char* a_rows = Ab + ((long long)tm * 256 + wave * 32) * sa1;     // sa1 == sa2 (checked on host)
+        const char* w_rows = reinterpret_cast<const char*>(a.W) + ((long long)tn * 256 + wave * 32) * sw + (long long)kt * 128;
+#pragma unroll
+        for (int inst = 0; inst < 4; ++inst) {
+            const unsigned x = (inst & 1) ? 64u : 0u;
+            glds16(a_rows + (long long)(inst * 8) * sa1 + (voff_a ^ x), at + (wave * 4 + inst) * 1024);
         }
-        stage_tile<256, NW>(reinterpret_cast<const char*>(a.W) + (long long)tn * 256 * sw + (long long)kt * 128, sw,
-                            at + A_BYTES, wave, lane, 256);
+        if (wave == 0 && part.e > 0) {
+            // 8 tail rows of this tile -> LDS rows 256..263 (row index 256 + lr: even-inst swizzle)
+            long long row = (long long)part.tail_base + (long long)tm * part.e + ((int)lr < part.e ? (int)lr : part.e - 1);
+            row = row < a.M ? row : a.M - 1;
+            glds16(Ab + row * sa1 + swz, at + 256 * 128);
+        }
+#pragma unroll
+        for (int inst = 0; inst < 4; ++inst) {
+            const unsigned x = (inst & 1) ? 64u : 0u;
+            glds16(w_rows + (long long)(inst * 8) * sw + (voff_w ^ x), at + A_BYTES + (wave * 4 + inst) * 1024);
+        }
     };
 
     f32x16 acc[TM][TN], accx;
+    // Fragment loads are software-pipelined: the 7 ds_read_b128 of k-step s+1 are issued between the
+    // 9 MFMAs of k-step s (sched_group_barrier pins that interleave), so only the first step of a
+    // k-tile exposes LDS latency.
+    // LDS fragment addresses: for lane (row tr, half h) the k-step s reads chunk (2s+h) ^ f(tr), and
+    // (2s+h) ^ f == ((h ^ f)) ^ 2s, so address(s) = address(0) ^ (s << 5): ONE offset register per
+    // fragment (7 in all) plus an XOR per read, instead of 28 hoisted address registers.
+    struct Frags { f32x4 a[TM], b[TN], x; };
+    unsigned a_off[TM], b_off[TN], x_off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int tr = wr * 128 + i * 32 + r32;
+        a_off[i] = tr * 128 + ((h ^ ((tr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int tr = wc * 64 + j * 32 + r32;
+        b_off[j] = A_BYTES + tr * 128 + ((h ^ ((tr >> 1) & 7)) << 4);
+    }
+    {
+        const int tr = 256 + r32;  // tail rows; rows >= 264 read the W tile's bytes: finite or not, they
+        x_off = tr * 128 + ((h ^ ((tr >> 1) & 7)) << 4);  // only reach dropped output columns
+    }
+    const unsigned smem_lds = lds_addr(smem);
+    typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+    // Called once per k-tile: makes the 7 offsets opaque to the optimiser so that it cannot hoist the
+    // 28 (offset ^ step) values out of the k-loop again (they would be spilled to scratch).
+    auto pin_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(a_off[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(b_off[j]));
+        asm volatile("" : "+v"(x_off));
+    };
+    auto load_frags = [&](unsigned stage_lds, int step, Frags& f) {
+        const unsigned sx = (unsigned)step << 5;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = *(lds_f32x4_ptr)(size_t)(stage_lds + (b_off[j] ^ sx));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = *(lds_f32x4_ptr)(size_t)(stage_lds + (a_off[i] ^ sx));
+        f.x = *(lds_f32x4_ptr)(size_t)(stage_lds + (x_off ^ sx));
+    };
+    auto mma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], f.b[j], f.a[i]);  // A-operand = W rows
+        mma_chunk<T>(accx, wr == 0 ? f.b[0] : f.b[1], f.x);
+    };
     auto compute = [&](int buf) {
         if (a.ablate & 4) return;
-        const char* Ab = smem + buf * k256Stage;
-        const char* Bb = Ab + A_BYTES + (wc * 64) * 128;
+        const unsigned st = smem_lds + buf * k256Stage;
+        pin_offsets();
+        Frags f0, f1;
+        load_frags(st, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);   // step 0's own fragments stay ahead of the MFMA region
+        load_frags(st, 1, f1);
+        mma_step(f0);
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
-            const int chunk = 2 * step + h;
-            f32x4 af[TM], bfr[TN], ax;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = j * 32 + r32, tr = wc * 64 + r;
-                bfr[j] = lds_read16(Bb + r * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int tr = wr * 128 + i * 32 + r32;
-                af[i] = lds_read16(Ab + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));
-            }
-            {
-                const int tr = 256 + r32;  // rows >= 264 read the W tile's bytes: finite or not, they
-                ax = lds_read16(Ab + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4));  // only reach dropped columns
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], bfr[j], af[i]);  // A-operand = W rows
-            mma_chunk<T>(accx, wr == 0 ? bfr[0] : bfr[1], ax);
+        for (int k = 0; k < 7; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        load_frags(st, 2, f0);
+        mma_step(f1);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        load_frags(st, 3, f1);
+        mma_step(f0);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        mma_step(f1);
     };
 
-    // one register quad (4 consecutive output columns of one row) through the fused epilogue math
-    auto finish = [&](f32x4 q, long long row, int col) -> f32x4 {
-        if (EPI != EPI_STORE && a.bias) q += *reinterpret_cast<const f32x4*>(a.bias + col);
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = gelu_erf<T>(q[e]);
-        }
-        if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
-            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + row * a.N + col);
-            if (EPI == EPI_BIAS_RESID) q = *xp + q;
-            *xp = q;
-        }
-        return q;
-    };
+    // Epilogue.  Two rules keep it from serialising on memory latency:
+    //  * no global LOAD may sit behind a global STORE of the same wave (vmcnt retires in order, so
+    //    a load's wait would also wait for every older store): the bias comes from LDS, and the
+    //    residual x is software-pipelined -- the loads of unit u+1 are issued BEFORE the stores of
+    //    unit u, so waiting for them only retires stores that are two units old;
+    //  * the bf16 copy leaves through the wave-private strip as whole 16-byte row segments.
     auto pack4 = [](const f32x4& q) -> uint2 {
         bf16_t o4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = f2bf(q[e]);
         return *reinterpret_cast<const uint2*>(o4);
     };
+    constexpr bool HAS_BIAS = EPI != EPI_STORE;
+    constexpr bool RESID = EPI == EPI_BIAS_RESID;
+    constexpr bool WRITES_X = EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET;
 
-    auto epilogue = [&](int lin) {
+    auto epilogue = [&](int lin, int parity) {
         const int tm = lin / n_tiles, tn = lin - tm * n_tiles;
         const bool use_out = EPI != EPI_BIAS_SET && a.out != nullptr;
+        const bool has_bias = HAS_BIAS && a.bias != nullptr;
         const int col0 = tn * 256 + wc * 64;
+        const unsigned bias_lds = lds_addr(smem + k256BiasOff + parity * 1024) + (wc * 64 + 4 * h) * 4;
+        // bias quads of column tile j: columns j*32 + 8g + 4h.., i.e. LDS bytes +32 per g
+        auto load_bias = [&](int j, f32x4 (&b)[4]) {
+            if (has_bias) asm_ds_read_4x_b128_wait(bias_lds + j * 128, b);
+            else b[0] = b[1] = b[2] = b[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        const long long row_base = (long long)tm * 256 + wr * 128 + r32;
+        auto xptr = [&](int i, int j, int g) {
+            return reinterpret_cast<f32x4*>(a.xres + (row_base + i * 32) * a.N + col0 + j * 32 + 8 * g + 4 * h);
+        };
+        f32x4 xl[2][4];   // residual quads of unit u = 2*i + j, double-buffered
+        if (RESID) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xl[0][g] = *xptr(0, 0, g);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long long row = (long long)tm * 256 + wr * 128 + i * 32 + r32;
-            f32x4 v[TN][4];
+            uint2 v[TN][4];   // bf16-packed results of this 32-row slab
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                const int u = i * TN + j;
+                f32x4 bias[4];
+                if (HAS_BIAS) load_bias(j, bias);
+                if (RESID && u + 1 < TM * TN) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xl[(u + 1) & 1][g] = *xptr((u + 1) / TN, (u + 1) % TN, g);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    v[j][g] = finish(q, row, col0 + j * 32 + 8 * g + 4 * h);
+                    f32x4 q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (HAS_BIAS) q += bias[g];
+                    if (EPI == EPI_BIAS_GELU && !(a.ablate & 8)) q = gelu_erf4<T>(q);
+                    if (RESID) q = xl[u & 1][g] + q;
+                    if (WRITES_X) *xptr(i, j, g) = q;
+                    v[j][g] = pack4(q);
                 }
+            }
             if (use_out) {
 #pragma unroll
                 for (int half16 = 0; half16 < 2; ++half16) {
@@ -445,7 +575,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) asm_ds_write_b64(sp + (j * 32 + 8 * g) * 2, pack4(v[j][g]));
+                            for (int g = 0; g < 4; ++g) asm_ds_write_b64(sp + (j * 32 + 8 * g) * 2, v[j][g]);
                     }
                     // 16 rows x 128 B back out as 16-byte row segments: 8 lanes per row, 8 rows per instruction
 #pragma unroll
@@ -453,7 +583,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                         const int sr = it * 8 + (lane >> 3), sc = lane & 7;
                         const f32x4 q = asm_ds_read_b128_wait(strip + sr * k256StripStride + sc * 16);
                         const long long orow = (long long)tm * 256 + wr * 128 + i * 32 + half16 * 16 + sr;
-                        *reinterpret_cast<f32x4*>(a.out + orow * a.ldo + col0 + sc * 8) = q;
+                        if (!(a.ablate & 16)) *reinterpret_cast<f32x4*>(a.out + orow * a.ldo + col0 + sc * 8) = q;
                     }
                 }
             }
@@ -461,23 +591,38 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         // tail rows: lane = tail row index (valid below part.e), registers = this wave's 32 columns
         if (part.e > 0) {
             const long long row = (long long)part.tail_base + (long long)tm * part.e + r32;
+            f32x4 bias[4];
+            if (HAS_BIAS) load_bias(wr, bias);
             if (r32 < part.e && row < a.M) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int col = col0 + wr * 32 + 8 * g + 4 * h;
                     f32x4 q = {accx[4 * g], accx[4 * g + 1], accx[4 * g + 2], accx[4 * g + 3]};
-                    q = finish(q, row, col);
+                    if (HAS_BIAS) q += bias[g];
+                    if (EPI == EPI_BIAS_GELU) q = gelu_erf4<T>(q);
+                    if (WRITES_X) {
+                        f32x4* xp = reinterpret_cast<f32x4*>(a.xres + row * a.N + col);
+                        if (RESID) q = *xp + q;
+                        *xp = q;
+                    }
                     if (use_out) *reinterpret_cast<uint2*>(a.out + row * a.ldo + col) = pack4(q);
                 }
             }
         }
     };
 
-    stage(tile_of(0), 0, 0);
+    int lin = tile_of(0);
+    int tm = lin / n_tiles, tn = lin - tm * n_tiles;
+    stage(tm, tn, 0, 0, 0, true);
     int buf = 0;
     bool stores_in_flight = false;
     for (int i = 0; i < n_my; ++i) {
-        const int lin = tile_of(i);
+        int lin_next = 0, tm_next = 0, tn_next = 0;
+        if (i + 1 < n_my) {
+            lin_next = tile_of(i + 1);
+            tm_next = lin_next / n_tiles;
+            tn_next = lin_next - tm_next * n_tiles;
+        }
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
@@ -491,14 +636,15 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
             if (kt == 0 && stores_in_flight) wait_vmcnt<N_EPI_STORES>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) stage(lin, kt + 1, buf ^ 1);
-            else if (i + 1 < n_my) stage(tile_of(i + 1), 0, buf ^ 1);
+            if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1, false);
+            else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1, false);
             compute(buf);
             buf ^= 1;
         }
-        if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) { stores_in_flight = false; continue; }
-        epilogue(lin);
+        if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) { stores_in_flight = false; lin = lin_next; tm = tm_next; tn = tn_next; continue; }
+        epilogue(lin, i & 1);
         stores_in_flight = true;
+        lin = lin_next; tm = tm_next; tn = tn_next;
     }
 }
 
@@ -541,7 +687,7 @@ int g_num_cus = 256;
 // Row partition for gemm256 (see the kernel's header): q main tiles, e tail rows per tile, chosen to
 // minimise rounds over the CUs; returns false when the shape does not fit the kernel.
 bool plan256(int M, int N, int K, int K1, Part256& p) {
-    if (N % 256 || K % 64 || K1 % 64 || M < 256) return false;
+    if (N % 256 || K % 64 || K1 % 64 || M < 256 || (long long)K * 2 * 8 >= (1ll << 31)) return false;
     const int nt = N / 256;
     const int q_hi = M / 256, q_lo = (M + 263) / 264;
     double best = 1e30;
@@ -627,7 +773,7 @@ hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, 
     } else {
         if (variant == 8) {
             Part256 p;
-            if (plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, epilogue, p, s);
+            if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, epilogue, p, s);
             variant = 0;  // shapes the 256x256 kernel does not take (small N, tiny M)
         }
         switch (variant) {
