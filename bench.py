@@ -179,6 +179,15 @@ def main():
         with torch.cuda.stream(stream):
             ms, fl = ef.bench_gemm(B, iters=50, stream=stream)
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM bytes of that kernel per launch from the committed two-pass PMC profile (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE; tools/pmc_summary.py) -- rocprofv3 cannot run inside this process
+        traffic = None
+        try:
+            pmc = json.load(open(REPO / "profiles" / "r01_pmc_traffic.json"))
+            k = next(v for n, v in pmc.items() if "gemm256_kernel<1>" in n)
+            traffic = (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6
+        except Exception:
+            pass
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
         out = {
             "metric": "images/sec (whole node) DuoDiff 1000-step CelebA-64",
@@ -192,8 +201,9 @@ def main():
                        "seconds_per_sample": (dt * 1000.0 / K) / images, "finite": finite,
                        "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "gemm_kernel<bf16,EPI_BIAS_GELU> fc1 M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
+                         "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes": (B * mp_f.seq_len * mp_f.embed_dim + 4 * mp_f.embed_dim * mp_f.embed_dim + B * mp_f.seq_len * 4 * mp_f.embed_dim) * 2,
+                         "kernel": "gemm256_kernel<EPI_BIAS_GELU> (fc1: bias + exact-erf GELU fused) M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
                          "ms_per_launch": ms, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS},
         }
