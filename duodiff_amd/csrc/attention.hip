@@ -33,7 +33,10 @@ template <> struct AttnLayout<float> {
     static constexpr int kRowV = kLP * 4 + 16;    // 292 dwords = 4 mod 64
 };
 
-template <typename T>
+// NKT > 0: the number of 32-key tiles is a compile-time constant (9 for L = 257/258: every shipped
+// config), which removes the per-tile uniform guards, confines the padded-key mask to the last tile's
+// 16 registers and takes ~1000 SGPR-spill lane moves out of the chunk body.  NKT == 0: generic L <= 288.
+template <typename T, int NKT>
 __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1)
 attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, int H, int D) {
     using Lay = AttnLayout<T>;
@@ -48,7 +51,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     const T* qbase = qkv + (long long)b * L * ld + hh * kHD;
     const T* kbase = qbase + D;
     const T* vbase = qbase + 2 * D;
-    const int nkt = (L + 31) / 32;                     // key tiles actually used
+    const int nkt = NKT > 0 ? NKT : (L + 31) / 32;     // key tiles actually used
     constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte chunk
     constexpr int CPR = kHD / EPC;                     // chunks per row (8 bf16 / 16 fp32)
 
@@ -128,13 +131,14 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (t < nkt) {
+                if (NKT > 0 ? t < NKT : t < nkt) {
                     const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
                         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
                         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[t], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's K reads from being hoisted (and spilled)
                 }
             }
         } else {
@@ -144,7 +148,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             for (int g = 0; g < 8; ++g) qf[g] = qcur[g];
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (t < nkt) {
+                if (NKT > 0 ? t < NKT : t < nkt) {
                     const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
@@ -163,8 +167,8 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < kMaxKeyTiles; ++t) {
-            if (t < nkt) {
-                if (t == nkt - 1) {
+            if (NKT > 0 ? t < NKT : t < nkt) {
+                if (NKT > 0 ? t == NKT - 1 : t == nkt - 1) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -181,7 +185,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < kMaxKeyTiles; ++t) {
-            if (t < nkt) {
+            if (NKT > 0 ? t < NKT : t < nkt) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float p;
@@ -205,7 +209,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (t < nkt) {
+                if (NKT > 0 ? t < NKT : t < nkt) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
@@ -225,12 +229,13 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
 #pragma unroll
             for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (t < nkt) {
+                if (NKT > 0 ? t < NKT : t < nkt) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         // registers 4g..4g+3 are keys t*32 + 8g + 4*half + (0..3): contiguous in V^T
@@ -275,16 +280,18 @@ hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hi
     if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
     using Lay = AttnLayout<T>;
     const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)kHD * Lay::kRowV;
-    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
+    if ((L + 31) / 32 == 9) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
+    else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     return hipGetLastError();
 }
 
 hipError_t init_attention_kernels() {
-    hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV);
+    const int lb = kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV;
+    const int lf = kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV;
+    hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<float, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lf);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lf);
     return e;
 }
 

@@ -543,6 +543,15 @@ int dd_ddpm_step(dd_ctx* c, const float* x_dev, const float* eps_dev, const floa
     return DD_OK;
 }
 
+int dd_affine_step(dd_ctx* c, const float* x_dev, const float* m_dev, const float* z_dev, float a, float b, float cc,
+                   float* out_dev, int64_t n, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    if (!x_dev || !m_dev || !out_dev || n < 0) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (n == 0) return DD_OK;
+    DD_HIP(c, launch_affine_step(x_dev, m_dev, z_dev, out_dev, a, b, cc, (long long)n, (hipStream_t)stream));
+    return DD_OK;
+}
+
 int dd_sample_step(dd_ctx* c, dd_model* m, float* x_dev, int t, const int64_t* y_dev, int noise_mode, const float* z_dev,
                    uint64_t seed, int variance, float* eps_out_dev, int B, void* stream) {
     int rc = check_call(c, m, B, y_dev);

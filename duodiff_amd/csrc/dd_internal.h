@@ -109,6 +109,8 @@ hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, float* out,
                             StepCoef c, int use_noise, long long n, hipStream_t s);
 template <typename T> hipError_t launch_fill_random(T* p, long long n, unsigned seed, float scale, hipStream_t s);
+hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
+                              long long n, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
 hipError_t launch_advance_state(StepState* st, hipStream_t s);

@@ -251,6 +251,19 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
     out[i] = v;
 }
 
+// out = a*x + b*m + c*z, each product rounded (no FMA contraction): the common form of the reference's
+// predict_original / predict_previous post-processing (sampler.py:59-79) and of a DDIM step (:112-120).
+__global__ void affine_step_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                   const float* __restrict__ z, float* __restrict__ out, float a, float b, float c,
+                                   long long n) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = a * x[i] + b * m[i];
+    if (z) v = v + c * z[i];
+    out[i] = v;
+}
+
 __global__ void set_state_kernel(StepState* st, int t, unsigned long long seed) {
     st->t = t;
     st->t_model = (float)t;
@@ -318,6 +331,12 @@ hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, fl
     // variance selection is folded by the caller into c.sigma_tilde
     hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, eps, z, out, c,
                        use_noise, 0, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
+                              long long n, hipStream_t s) {
+    hipLaunchKernelGGL(affine_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, m, z, out, a, b, c, n);
     return hipGetLastError();
 }
 

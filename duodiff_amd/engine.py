@@ -75,6 +75,14 @@ class Context:
                                          _ptr(out), x.numel(), _stream_ptr(stream)))
         return out
 
+    def affine_step(self, x, m, z, a, b, c, out=None, stream=None):
+        """out = a*x + b*m + c*z on device tensors (z may be None)."""
+        out = torch.empty_like(x) if out is None else out
+        self.check(self.lib.dd_affine_step(self.handle, _ptr(x.contiguous()), _ptr(m.contiguous()),
+                                           _ptr(z.contiguous() if z is not None else None), float(a), float(b),
+                                           float(c), _ptr(out), x.numel(), _stream_ptr(stream)))
+        return out
+
     def dev_gemm(self, M, N, K, variant=0, epilogue=0, iters=20, check=False, stream=None):
         """Development harness: time one bf16 GEMM variant; returns (ms, TFLOP/s, mismatches vs variant 0)."""
         ms, mm = C.c_float(), C.c_longlong()

@@ -10,8 +10,9 @@ bit-identical noise for parity runs).
         --config_path_late configs/uvit_celeba.yaml --checkpoint_path_late f.pth --t_switch 300 \
         --batch_size 128 --parametrization predict_noise --output_folder out
 
-Out of scope this round: DDIM (--use_ddim), predict_original / predict_previous,
-the KL-VAE decode of ImageNet-256 latents.
+DDIM (--use_ddim) and the predict_original / predict_previous parametrizations run
+the U-ViT forward on the engine plus one fused affine update per step.  Out of scope this round: the KL-VAE
+decode of ImageNet-256 latents (next-1).
 """
 import math
 import random
@@ -71,12 +72,50 @@ def predict_noise_postprocessing(model_output, x, t, z=None):
     return ctx.ddpm_step(x.contiguous(), model_output, z if t > 0 else None, t)
 
 
-def predict_original_postprocessing(model_output, x, t):
-    raise NotImplementedError("predict_original is outside the accelerated path (SURVEY section 8f, next-2)")
+def _f32(v):
+    return np.float32(v)
 
 
-def predict_previous_postprocessing(model_output, x, t):
-    raise NotImplementedError("predict_previous is outside the accelerated path (SURVEY section 8f, next-2)")
+def affine_coefficients(kind, t, s=None, eta=0.0):
+    """Scalar (a, b, c) with x' = a*x + b*model_output + c*z for the reference's other updates, in fp32
+    from the engine's (bit-exact) tables:
+      "predict_original"  sampler.py:59-72      "predict_previous"  sampler.py:75-79
+      "ddim" (t -> s)     sampler.py:112-120 (noise scaled by sigma^2 = betas_tilde[t]*eta, as the reference does)
+    """
+    tb = schedule_tables()
+    one = _f32(1)
+    if kind == "predict_previous":
+        return _f32(0), one, np.sqrt(tb["betas_tilde"][t])
+    if kind == "predict_original":
+        a_t, ab_t, ab_p, b_t = tb["alphas"][t], tb["alphas_bar"][t], tb["alphas_bar_previous"][t], tb["betas"][t]
+        a = _f32(np.sqrt(a_t) * (one - ab_p)) / (one - ab_t)
+        b = _f32(np.sqrt(ab_p) * b_t) / (one - ab_t)
+        return _f32(a), _f32(b), np.sqrt(tb["betas_tilde"][t])
+    if kind == "ddim":
+        ab = tb["alphas_bar"]
+        sig2 = _f32(tb["betas_tilde"][t] * _f32(eta))
+        a = np.sqrt(_f32(ab[s] / ab[t]))
+        b = _f32(np.sqrt(_f32(one - ab[s] - sig2)) - _f32(a * np.sqrt(_f32(one - ab[t]))))
+        return _f32(a), b, sig2
+    raise ValueError(kind)
+
+
+def _affine_post(kind, model_output, x, t, z=None):
+    ctx = Context.get(x.device)
+    a, b, c = affine_coefficients(kind, t)
+    if t > 0 and z is None:
+        z = torch.randn(x.shape).to(x.device)          # randn_like on the torch CPU stream (sampler.py:67,77)
+    return ctx.affine_step(x, model_output, z if t > 0 else None, a, b, c)
+
+
+def predict_original_postprocessing(model_output, x, t, z=None):
+    """reference sampler.py:59-72 (model predicts x_0) on device tensors."""
+    return _affine_post("predict_original", model_output, x, t, z)
+
+
+def predict_previous_postprocessing(model_output, x, t, z=None):
+    """reference sampler.py:75-79 (model predicts x_{t-1}) on device tensors."""
+    return _affine_post("predict_previous", model_output, x, t, z)
 
 
 def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num_channels: int,
@@ -91,10 +130,6 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     noise="device": x_T as above, z from the device Philox generator inside the graph-replayed loop.
     num_steps < 1000 runs only the first steps (t = 999 ...), for bounded benchmarks.
     """
-    if use_ddim:
-        raise NotImplementedError("DDIM sampling is outside the accelerated path (SURVEY section 8f, next-2)")
-    if postprocessing is not predict_noise_postprocessing:
-        raise NotImplementedError("only the predict_noise parametrization is accelerated")
     if autoencoder is not None:
         raise NotImplementedError("KL-VAE decode is outside the accelerated path (SURVEY section 8f, next-1)")
     device = model.device
@@ -110,7 +145,41 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     ctx = first.ctx
     switch_t = 1000 - t_switch if (late is not None and np.isfinite(t_switch)) else None
 
-    if noise == "device":
+    def draw(shape):
+        return torch.randn(shape).to(device) if noise == "torch_cpu" else torch.randn(shape, device=device)
+
+    if use_ddim:
+        # reference sampler.py:103-126.  U-ViT forward on the engine + one fused affine update per step.
+        eps = torch.empty_like(x)
+        cur = first
+        ts = np.linspace(0, 999, ddim_steps).astype(int)[::-1]
+        for t, s_ in zip(ts[:-1], ts[1:]):
+            t, s_ = int(t), int(s_)
+            cur.forward(x, float(t), y, out=eps)                             # :108-110
+            a, b, c = affine_coefficients("ddim", t, s_, ddim_eta)           # :112-117
+            z = draw(x.shape) if s_ > 0 else None                            # :119
+            ctx.affine_step(x, eps, z, a, b, c, out=x)                       # :120
+            if late is not None and t < 1000 - t_switch:                     # :122-123
+                cur = late
+            if 1000 - t in saves:                                            # :125-126
+                intermediate.append(x.clone())
+    elif postprocessing is not predict_noise_postprocessing:
+        # predict_original / predict_previous (sampler.py:59-79): same loop, affine update
+        kind = {predict_original_postprocessing: "predict_original",
+                predict_previous_postprocessing: "predict_previous"}.get(postprocessing)
+        if kind is None:
+            raise ValueError("postprocessing must be one of this module's predict_*_postprocessing functions")
+        eps = torch.empty_like(x)
+        cur = first
+        for t in range(999, t_last - 1, -1):
+            cur.forward(x, float(t), y, out=eps)
+            a, b, c = affine_coefficients(kind, t)
+            ctx.affine_step(x, eps, draw(x.shape) if t > 0 else None, a, b, c, out=x)
+            if switch_t is not None and t == switch_t:
+                cur = late
+            if 1000 - t in saves:
+                intermediate.append(x.clone())
+    elif noise == "device":
         # segments between save points; each segment is one dd_sample call (graph replays)
         stops = sorted({1000 - s for s in saves if t_last <= 1000 - s <= 999}, reverse=True)
         t = 999

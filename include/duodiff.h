@@ -109,6 +109,12 @@ int dd_forward(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const floa
 int dd_ddpm_step(dd_ctx* ctx, const float* x_dev, const float* eps_dev, const float* z_dev,
                  int t, int variance, float* x_out_dev, int64_t n, void* stream);
 
+/* ---- generic scalar-affine update: out = a*x + b*m + c*z (z_dev may be NULL) ---------- */
+/* The form shared by predict_original / predict_previous post-processing (sampler.py:59-79) and a
+ * DDIM step (sampler.py:112-120); the host computes a, b, c from the schedule tables. */
+int dd_affine_step(dd_ctx* ctx, const float* x_dev, const float* m_dev, const float* z_dev, float a,
+                   float b, float c, float* out_dev, int64_t n, void* stream);
+
 /* ---- one fused sampling step: x <- step(x, model(x,t,y), t) in place ---------------- */
 /* noise_mode DD_NOISE_BUFFER: z_dev [B,C,S,S] supplies z (parity with the torch CPU stream);
  * DD_NOISE_PHILOX: z is generated on the device from (seed, t, element);

@@ -15,6 +15,9 @@ from .schedule_oracle import (  # noqa: F401
     sampler_schedule,
     scheduler_schedule,
     ddpm_step,
+    predict_original_step,
+    predict_previous_step,
+    ddim_step,
 )
 from .uvit_oracle import (  # noqa: F401
     UViTOracle,
@@ -28,4 +31,4 @@ from .uvit_oracle import (  # noqa: F401
     conv3x3,
 )
 from .uvit_oracle_torch import UViTTorchOracle  # noqa: F401
-from .sampling_oracle import get_samples, scheduler_sample, seed_everything  # noqa: F401
+from .sampling_oracle import get_samples, get_samples_ddim, scheduler_sample, seed_everything  # noqa: F401

@@ -16,6 +16,8 @@ Fixtures:
   rollout_tiny.npz    F4  get_samples with late_model, t_switch=300, seed 0, B=2
   uvit_full_*.npz     F5  full-size forwards (B=2) of the shipped YAMLs: slice + stats + checksum
   rng.npz             F6  first values of the torch CPU randn stream after seed_everything(0)
+  param_steps.npz         predict_original / predict_previous post-processing (sampler.py:59-79)
+  ddim_tiny.npz           get_samples(use_ddim=True) rollouts incl. late-model switch (sampler.py:103-126)
   scheduler_tiny.npz      NoiseScheduler.sample with the tiny model (ddpm_core loop)
 """
 import contextlib
@@ -205,6 +207,39 @@ def gen_full():
         print(name, "eps std", float(eps.std()), flush=True)
 
 
+def gen_param():
+    """predict_original / predict_previous post-processing (sampler.py:59-79) on fixed inputs."""
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    m = torch.randn(2, 3, 8, 8, generator=g)
+    out = dict(x=x.numpy(), m=m.numpy(), ts=np.array([999, 500, 1, 0]))
+    for t in (999, 500, 1, 0):
+        torch.manual_seed(2000 + t)
+        out[f"z_{t}"] = torch.randn(x.shape).numpy()
+        torch.manual_seed(2000 + t)
+        out[f"orig_{t}"] = ref_sampler.predict_original_postprocessing(m, x, t).numpy()
+        torch.manual_seed(2000 + t)
+        out[f"prev_{t}"] = ref_sampler.predict_previous_postprocessing(m, x, t).numpy()
+    np.savez(OUT / "param_steps.npz", **out)
+
+
+def gen_ddim():
+    """get_samples(use_ddim=True) with the tiny shallow+full pair (sampler.py:103-126)."""
+    m_s, mp = build_ref(dict(TINY, depth=1), seed=300)
+    m_f, _ = build_ref(dict(TINY, depth=3), seed=301)
+    out = {}
+    for tag, steps, eta, tsw in (("a", 20, 0.0, 300), ("b", 10, 0.5, 600)):
+        with contextlib.redirect_stderr(io.StringIO()):
+            samples, inter = ref_sampler.get_samples(
+                model=m_s, batch_size=2, postprocessing=ref_sampler.predict_noise_postprocessing, seed=3,
+                num_channels=3, sample_height=8, sample_width=8, use_ddim=True, ddim_steps=steps, ddim_eta=eta,
+                timesteps_save=[1], y=None, autoencoder=None, late_model=m_f, t_switch=tsw)
+        out[f"samples_{tag}"] = samples
+        out[f"first_{tag}"] = inter[0]
+        out[f"cfg_{tag}"] = np.array([steps, eta, tsw], np.float64)
+    np.savez(OUT / "ddim_tiny.npz", **out)
+
+
 def gen_rng():
     ref_seed_everything(0)
     a = torch.randn(64)
@@ -219,7 +254,7 @@ def gen_rng():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "full"]
+    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "full"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -14,7 +14,8 @@ import random
 import numpy as np
 import torch
 
-from .schedule_oracle import ddpm_step, sampler_schedule, scheduler_schedule
+from .schedule_oracle import (ddim_step, ddpm_step, predict_original_step, predict_previous_step, sampler_schedule,
+                              scheduler_schedule)
 
 F32 = np.float32
 
@@ -77,3 +78,30 @@ def scheduler_sample(model, num_steps, data_shape, num_samples, seed, variance_m
         x = ddpm_step(x, eps, z, t, tables, variance=variance)               # :190-193
         over_time.append(x)                                                  # :210
     return x, over_time
+
+
+def get_samples_ddim(model, batch_size, seed, num_channels, sample_height, sample_width, ddim_steps=50, ddim_eta=0.0,
+                     timesteps_save=(), y=None, late_model=None, t_switch=np.inf):
+    """sampler.py:103-126: the DDIM branch of get_samples, including its two quirks (sigma^2-scaled noise;
+    the late model takes over once t < 1000 - t_switch, tested AFTER the step)."""
+    tables = sampler_schedule()
+    seed_everything(seed)
+    x = torch.randn(batch_size, num_channels, sample_height, sample_width).numpy()
+    inter = []
+    ts = np.linspace(0, 999, ddim_steps).astype(int)[::-1]
+    for t, s in zip(ts[:-1], ts[1:]):
+        t, s = int(t), int(s)
+        eps = model(x, (F32(t) * np.ones(batch_size, F32)).astype(F32), y)
+        z = torch.randn(x.shape).numpy() if s > 0 else None
+        x = ddim_step(x, eps, z, t, s, ddim_eta, tables)
+        if t < 1000 - t_switch:
+            model = late_model
+        if 1000 - t in timesteps_save:
+            inter.append(x)
+    samples = ((x + F32(1)) / F32(2)).astype(F32).transpose(0, 2, 3, 1)
+    inter = [((v + F32(1)) / F32(2)).astype(F32).transpose(0, 2, 3, 1) for v in inter]
+    return np.ascontiguousarray(samples), inter
+
+
+POSTPROCESSING = {"predict_noise": ddpm_step, "predict_original": predict_original_step,
+                  "predict_previous": predict_previous_step}

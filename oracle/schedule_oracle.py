@@ -97,3 +97,40 @@ def ddpm_step(x, eps, z, t, tables=None, variance="beta_tilde"):
     if t > 0 and z is not None:
         return (mean + (sigma * np.asarray(z, F32)).astype(F32)).astype(F32)
     return mean
+
+
+def predict_original_step(x, m, z, t, tables=None):
+    """reference sampler.py:59-72 (model predicts x_0)."""
+    tb = tables or sampler_schedule()
+    a_t, ab_t, ab_p, b_t = tb["alphas"][t], tb["alphas_bar"][t], tb["alphas_bar_previous"][t], tb["betas"][t]
+    sigma = np.sqrt(tb["betas_tilde"][t], dtype=F32)
+    x, m = np.asarray(x, F32), np.asarray(m, F32)
+    t1 = ((np.sqrt(ab_p, dtype=F32) * b_t).astype(F32) * m).astype(F32) / (F32(1) - ab_t)
+    t2 = ((np.sqrt(a_t, dtype=F32) * (F32(1) - ab_p)).astype(F32) * x).astype(F32) / (F32(1) - ab_t)
+    out = (t1.astype(F32) + t2.astype(F32)).astype(F32)
+    if t > 0 and z is not None:
+        out = (out + (sigma * np.asarray(z, F32)).astype(F32)).astype(F32)
+    return out
+
+
+def predict_previous_step(x, m, z, t, tables=None):
+    """reference sampler.py:75-79 (model predicts x_{t-1})."""
+    tb = tables or sampler_schedule()
+    sigma = np.sqrt(tb["betas_tilde"][t], dtype=F32)
+    out = np.asarray(m, F32)
+    if t > 0 and z is not None:
+        out = (out + (sigma * np.asarray(z, F32)).astype(F32)).astype(F32)
+    return out
+
+
+def ddim_step(x, m, z, t, s, eta, tables=None):
+    """One DDIM update t -> s of reference sampler.py:112-120 (note: noise is scaled by sigma^2, as there)."""
+    tb = tables or sampler_schedule()
+    ab = tb["alphas_bar"]
+    sig2 = F32(tb["betas_tilde"][t] * F32(eta))
+    x, m = np.asarray(x, F32), np.asarray(m, F32)
+    mean = (np.sqrt(ab[s] / ab[t], dtype=F32) * (x - (np.sqrt(F32(1) - ab[t], dtype=F32) * m).astype(F32)).astype(F32)).astype(F32)
+    mean = (mean + (np.sqrt(F32(1) - ab[s] - sig2, dtype=F32) * m).astype(F32)).astype(F32)
+    if s > 0 and z is not None:
+        return (mean + (sig2 * np.asarray(z, F32)).astype(F32)).astype(F32)
+    return mean

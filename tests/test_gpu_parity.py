@@ -230,3 +230,34 @@ def test_error_behaviour_matches_reference_classes():
     u = UViT(**ModelParams.from_dict(dict(TINY)).as_dict())
     with pytest.raises(RuntimeError):
         u(torch.zeros(1, 3, 8, 8), torch.zeros(1))     # no weights loaded
+
+
+def test_ddim_and_other_parametrizations_vs_reference(golden):
+    """SURVEY section 8f next-2 on the GPU (fp32 mode): DDIM rollouts incl. late-model switch against the reference's
+    own outputs, and the predict_original / predict_previous updates against the reference."""
+    from duodiff_amd import sampler
+    fd = golden("ddim_tiny.npz")
+    for tag in ("a", "b"):
+        steps, eta, tsw = fd[f"cfg_{tag}"]
+        m_s, _ = _uvit(dict(TINY, depth=1), 300, "fp32")
+        m_f, _ = _uvit(dict(TINY, depth=3), 301, "fp32")
+        samples, inter = sampler.get_samples(m_s, 2, sampler.predict_noise_postprocessing, 3, 3, 8, 8, use_ddim=True,
+                                             ddim_steps=int(steps), ddim_eta=float(eta), timesteps_save=[1],
+                                             late_model=m_f, t_switch=int(tsw), noise="torch_cpu")
+        np.testing.assert_allclose(inter[0], fd[f"first_{tag}"], rtol=0, atol=1e-5)
+        scale = max(1.0, float(np.abs(fd[f"samples_{tag}"]).max()))
+        np.testing.assert_allclose(samples, fd[f"samples_{tag}"], rtol=0, atol=2e-4 * scale)
+    fx = golden("param_steps.npz")
+    x, m = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["m"]).cuda()
+    for t in fx["ts"]:
+        t = int(t)
+        z = torch.from_numpy(fx[f"z_{t}"]).cuda()
+        got = sampler.predict_original_postprocessing(m, x, t, z).cpu().numpy()
+        ref = fx[f"orig_{t}"]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(1.0, float(np.abs(ref).max())))
+        got = sampler.predict_previous_postprocessing(m, x, t, z).cpu().numpy()
+        np.testing.assert_allclose(got, fx[f"prev_{t}"], rtol=0, atol=1e-6)
+    # a short predict_previous loop runs end to end through get_samples
+    m_s, _ = _uvit(dict(TINY, depth=1), 300, "bf16")
+    s, _ = sampler.get_samples(m_s, 2, sampler.predict_previous_postprocessing, 0, 3, 8, 8, num_steps=5, noise="torch_cpu")
+    assert s.shape == (2, 8, 8, 3) and np.isfinite(s).all()

@@ -112,8 +112,7 @@ def test_cli_arguments_match_reference_surface():
     assert a.timesteps_save == [] and a.precision == "bf16"
     with pytest.raises(SystemExit):
         sampler.get_args(["--batch_size", "4"])
-    with pytest.raises(NotImplementedError):
-        sampler.predict_original_postprocessing(None, None, 0)
+    assert a.noise == "device" and a.no_graph is False
 
 
 def test_model_param_validation_through_c_abi():

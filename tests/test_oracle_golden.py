@@ -150,3 +150,43 @@ def test_torch_functional_oracle_tiny(golden, name):
     m = oracle.UViTTorchOracle(cfg, synthetic_state_dict(mp, int(fx["seed"])))
     eps = m(fx["x"], fx["t"], fx["y"] if "y" in fx.files else None)
     np.testing.assert_allclose(eps, fx["eps"], rtol=0, atol=1e-5)
+
+
+def test_other_parametrizations_and_ddim_vs_reference(golden):
+    """predict_original / predict_previous updates and the DDIM branch."""
+    fx = golden("param_steps.npz")
+    for t in fx["ts"]:
+        t = int(t)
+        np.testing.assert_allclose(oracle.predict_original_step(fx["x"], fx["m"], fx[f"z_{t}"], t), fx[f"orig_{t}"],
+                                   rtol=0, atol=2e-6 * max(1.0, float(np.abs(fx[f"orig_{t}"]).max())))
+        np.testing.assert_allclose(oracle.predict_previous_step(fx["x"], fx["m"], fx[f"z_{t}"], t), fx[f"prev_{t}"],
+                                   rtol=0, atol=1e-6)
+    fd = golden("ddim_tiny.npz")
+    from conftest import TINY
+    mp_s, mp_f = ModelParams.from_dict(dict(TINY, depth=1)), ModelParams.from_dict(dict(TINY, depth=3))
+    for tag in ("a", "b"):
+        steps, eta, tsw = fd[f"cfg_{tag}"]
+        m_s = oracle.UViTOracle(mp_s.as_dict(), _params(mp_s, 300))
+        m_f = oracle.UViTOracle(mp_f.as_dict(), _params(mp_f, 301))
+        samples, inter = oracle.get_samples_ddim(m_s, 2, 3, 3, 8, 8, ddim_steps=int(steps), ddim_eta=float(eta),
+                                                 timesteps_save=[1], late_model=m_f, t_switch=int(tsw))
+        np.testing.assert_allclose(inter[0], fd[f"first_{tag}"], rtol=0, atol=1e-5)
+        scale = max(1.0, float(np.abs(fd[f"samples_{tag}"]).max()))
+        np.testing.assert_allclose(samples, fd[f"samples_{tag}"], rtol=0, atol=1e-4 * scale)
+        assert m_s.calls + m_f.calls == int(steps) - 1 and m_f.calls > 0
+
+
+def test_affine_coefficients_reproduce_reference_updates(golden):
+    """Host-side scalar coefficients (duodiff_amd.sampler.affine_coefficients) against the reference's outputs."""
+    from duodiff_amd import sampler
+    fx = golden("param_steps.npz")
+    for t in fx["ts"]:
+        t = int(t)
+        for kind, key in (("predict_original", "orig"), ("predict_previous", "prev")):
+            a, b, c = sampler.affine_coefficients(kind, t)
+            got = a * fx["x"] + b * fx["m"] + (c * fx[f"z_{t}"] if t > 0 else 0)
+            ref = fx[f"{key}_{t}"]
+            np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(1.0, float(np.abs(ref).max())))
+    a, b, c = sampler.affine_coefficients("ddim", 999, 946, 0.5)
+    x, m, z = fx["x"], fx["m"], fx["z_999"]
+    np.testing.assert_allclose(a * x + b * m + c * z, oracle.ddim_step(x, m, z, 999, 946, 0.5), rtol=0, atol=2e-5)
