@@ -79,23 +79,23 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
         for (int e = 0; e < 4; ++e) r[e] = gelu_erf<T>(v[e]);
         return r;
     } else {
-        const f32x4 ax = __builtin_elementwise_abs(v);
-        const f32x4 x = ax * 0.70710678118654752440f;
-        const f32x4 d = x * 0.3275911f + 1.0f;
+        // bf16 mode: erf from Abramowitz-Stegun 7.1.25, erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) e^{-z^2},
+        // t = 1/(1 + 0.47047 z), |error| <= 2.5e-5 -- two orders below the bf16 rounding of the
+        // output -- with z = |v|/sqrt2 folded into the constants.  7 VALU issue slots per element:
+        //   gelu(v) = 0.5 (v + |v|) - |v| * (0.5 poly(t)) * exp2(-|v|^2 log2(e)/2)
+        const f32x4 u = __builtin_elementwise_abs(v);
+        const f32x4 d = u * (0.47047f * 0.70710678118654752440f) + 1.0f;
         f32x4 t, e;
 #pragma unroll
         for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(d[i]);
-        f32x4 p = t * 1.061405429f + (-1.453152027f);
-        p = p * t + 1.421413741f;
-        p = p * t + (-0.284496736f);
-        p = p * t + 0.254829592f;
-        p = p * t;
-        const f32x4 a2 = x * x * (-1.4426950408889634f);
+        f32x4 q = t * (0.5f * 0.7478556f) + (0.5f * -0.0958798f);
+        q = q * t + (0.5f * 0.3480242f);
+        q = q * t;
+        const f32x4 a2 = (u * u) * (-0.5f * 1.4426950408889634f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a2[i]);
-        // 0.5 v (1 + erf(v/sqrt2)) with erf(|z|) = 1 - p e  ==>  gelu(v) = 0.5 (v + |v|) - 0.5 |v| p e
-        const f32x4 w = (ax * 0.5f) * (p * e);
-        return (v + ax) * 0.5f - w;
+        const f32x4 w = u * (q * e);
+        return (v + u) * 0.5f - w;
     }
 }
 
@@ -515,11 +515,10 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     //    residual x is software-pipelined -- the loads of unit u+1 are issued BEFORE the stores of
     //    unit u, so waiting for them only retires stores that are two units old;
     //  * the bf16 copy leaves through the wave-private strip as whole 16-byte row segments.
-    auto pack4 = [](const f32x4& q) -> uint2 {
-        bf16_t o4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = f2bf(q[e]);
-        return *reinterpret_cast<const uint2*>(o4);
+    auto pack4 = [](const f32x4& q) -> uint2 {   // two v_cvt_pk_bf16_f32, no mask/shift glue
+        typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+        const bf16v4 b = __builtin_convertvector(q, bf16v4);
+        return __builtin_bit_cast(uint2, b);
     };
     constexpr bool HAS_BIAS = EPI != EPI_STORE;
     constexpr bool RESID = EPI == EPI_BIAS_RESID;
@@ -745,6 +744,7 @@ hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipS
 // that launches are capturable into a hipGraph)
 hipError_t init_gemm_kernels() {
     hipError_t e = init_cfg<float, 128, 128, 2, 2, 2>();
+    if (e == hipSuccess) e = init_cfg<float, 128, 64, 2, 2, 2>();
 #define X(ID, BM, BN, WM, WN, ST) \
     if (e == hipSuccess) e = init_cfg<bf16_t, BM, BN, WM, WN, ST>();
     DD_VARIANTS(X)
@@ -769,6 +769,7 @@ hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, 
     constexpr int KT = 128 / (int)sizeof(T);
     if (a.K % KT || a.K1 % KT || a.K1 > a.K || (a.K1 < a.K && !a.A2)) return hipErrorInvalidValue;
     if constexpr (sizeof(T) == 4) {
+        if (a.N <= 64) return launch_cfg<T, 128, 64, 2, 2, 2>(a, epilogue, s);  // decoder_pred: N = P*P*C <= 64
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
     } else {
         if (variant == 8) {

@@ -85,6 +85,95 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedArgs a) {
     }
 }
 
+// Fast path for D % 256 == 0 (every shipped config): 64 token rows per workgroup, each thread owns
+// ND = D/256 embedding columns and keeps their PD = C*P*P patch-embed weights in registers, so the
+// inner loop is PD LDS-broadcast reads + ND*PD FMAs per token with no global weight traffic.
+template <int ND, int PD>
+__global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
+    constexpr int TOK = 64;
+    __shared__ __attribute__((aligned(16))) float patch[TOK][PD];
+    const int chunks = (a.L + TOK - 1) / TOK;
+    const int b = blockIdx.x / chunks, r0 = (blockIdx.x % chunks) * TOK;
+    const int tid = threadIdx.x;
+    const int g = a.S / a.P, PP = a.P * a.P;
+    if (b >= a.B) {  // padding rows of the workspace
+        const long long row0 = (long long)a.B * a.L + (long long)(blockIdx.x - a.B * chunks) * TOK;
+        for (int j = 0; j < TOK; ++j) {
+            const long long row = row0 + j;
+            if (row < a.Mp)
+                for (int d = tid; d < a.D; d += 256) a.x_tok[row * a.D + d] = 0.f;
+        }
+        return;
+    }
+    for (int idx = tid; idx < TOK * PD; idx += 256) {
+        const int j = idx / PD, k = idx % PD, row = r0 + j;
+        float v = 0.f;
+        if (row >= a.extras && row < a.L) {
+            const int n = row - a.extras, gy = n / g, gx = n % g;
+            const int c = k / PP, p1 = (k / a.P) % a.P, p2 = k % a.P;
+            v = a.x_img[(((long long)b * a.C + c) * a.S + gy * a.P + p1) * a.S + gx * a.P + p2];
+        }
+        patch[j][k] = v;
+    }
+    float w[ND][PD], bias[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+        bias[n] = a.bias[tid + 256 * n];
+#pragma unroll
+        for (int k = 0; k < PD; ++k) w[n][k] = a.wt[(long long)k * a.D + tid + 256 * n];
+    }
+    __syncthreads();
+    const float t_raw = a.t_vec ? a.t_vec[b] : a.st->t_model;
+    const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
+    const int halfd = a.D / 2;
+    // pos_embed of row j+1 is requested BEFORE row j is stored: a load queued behind a store of the same
+    // wave would wait for that store (vmcnt retires in order) and serialise the loop on write latency
+    float pos_next[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) pos_next[n] = r0 < a.L ? a.pos[(long long)r0 * a.D + tid + 256 * n] : 0.f;
+    for (int j = 0; j < TOK; ++j) {
+        const int row = r0 + j;
+        if (row >= a.L) break;
+        float acc[ND], pos_cur[ND];
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            pos_cur[n] = pos_next[n];
+            if (row + 1 < a.L && j + 1 < TOK) pos_next[n] = a.pos[(long long)(row + 1) * a.D + tid + 256 * n];
+        }
+        if (row >= a.extras) {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) acc[n] = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < PD / 4; ++k4) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < ND; ++n) acc[n] = fmaf(w[n][k4 * 4 + e], p[e], acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < ND; ++n) acc[n] += bias[n];
+        } else if (row == a.extras - 1) {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) {
+                const int d = tid + 256 * n, i = d < halfd ? d : d - halfd;
+                const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
+                acc[n] = d < halfd ? cosf(arg) : sinf(arg);
+            }
+        } else {
+            long long yy = a.y[b];
+            yy = yy < 0 ? 0 : (yy >= a.num_classes ? a.num_classes - 1 : yy);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) acc[n] = a.label_emb[yy * a.D + tid + 256 * n];
+        }
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            const int d = tid + 256 * n;
+            a.x_tok[((long long)b * a.L + row) * a.D + d] = acc[n] + pos_cur[n];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5, biased variance, affine): one wave per token row, row held in registers,
 // two-pass statistics.  fp32 in, T out (the GEMM operand type).
@@ -167,21 +256,21 @@ __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigne
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 
-__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long elem, int t) {
-    unsigned c0 = (unsigned)(elem >> 2), c1 = (unsigned)((elem >> 2) >> 32), c2 = (unsigned)t, c3 = 0x5eedu;
+// four N(0,1) values for one pixel (one per channel, C <= 4): counter = (pixel, t), key = seed
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned long long pixel, int t) {
+    unsigned c0 = (unsigned)pixel, c1 = (unsigned)(pixel >> 32), c2 = (unsigned)t, c3 = 0x5eedu;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         philox_round(c0, c1, c2, c3, k0, k1);
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    const int sel = (int)(elem & 3);
-    const unsigned ua = (sel < 2) ? c0 : c2, ub = (sel < 2) ? c1 : c3;
-    const float u1 = ((float)ua + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
-    const float u2 = (float)ub * 2.3283064365386963e-10f;           // [0, 1)
-    const float rad = sqrtf(-2.0f * logf(u1));
-    const float ang = 6.283185307179586f * u2;
-    return (sel & 1) ? rad * sinf(ang) : rad * cosf(ang);
+    // Box-Muller on (c0,c1) and (c2,c3); hardware log/sin/cos (|error| ~1e-6) are ample for noise
+    const float ua = ((float)c0 + 1.0f) * 2.3283064365386963e-10f, ub = (float)c1 * 2.3283064365386963e-10f;
+    const float uc = ((float)c2 + 1.0f) * 2.3283064365386963e-10f, ud = (float)c3 * 2.3283064365386963e-10f;
+    const float ra = sqrtf(-2.0f * __logf(ua)), rc = sqrtf(-2.0f * __logf(uc));
+    const float aa = 6.283185307179586f * ub, ac = 6.283185307179586f * ud;
+    return f32x4{ra * __cosf(aa), ra * __sinf(aa), rc * __cosf(ac), rc * __sinf(ac)};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -224,6 +313,8 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
     const int t = a.st->t;
     const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
+    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+    if (a.x_out && t > 0 && a.noise_mode == 2) zn = philox_normal4(a.st->seed, (unsigned long long)pix, t);
     for (int co = 0; co < C; ++co) {
         const long long e = (((long long)b * C + co) * S + y) * S + x;
         const float eps = acc[co];
@@ -233,7 +324,65 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
             float v = cf.c1 * (a.x_in[e] - cf.c2 * eps);
             if (t > 0) {
                 if (a.noise_mode == 1) v = v + sigma * a.z[e];
-                else if (a.noise_mode == 2) v = v + sigma * philox_normal(a.st->seed, (unsigned long long)e, t);
+                else if (a.noise_mode == 2) v = v + sigma * zn[co];
+            }
+            a.x_out[e] = v;
+        }
+    }
+}
+
+// Tiled variant of final_kernel: a workgroup owns a 16x16 pixel tile of one image and first parks the
+// 18x18xC halo of the unpatchified decoder output in LDS, so every decoder value is fetched once
+// instead of up to nine times.  Same arithmetic, same rounding order.
+__global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
+#pragma clang fp contract(off)
+    __shared__ float u[4][18][19];
+    const int S = a.S, P = a.P, C = a.C, g = S / P, pd = P * P * C;
+    const int tiles = (S + 15) / 16;
+    const int b = blockIdx.x / (tiles * tiles), ty = (blockIdx.x / tiles) % tiles, tx = blockIdx.x % tiles;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 18 * 18; idx += 256) {
+        const int hy = idx / 18, hx = idx % 18;
+        const int yy = ty * 16 + hy - 1, xx = tx * 16 + hx - 1;
+        const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+        const float* src = a.dec + ((long long)b * a.L + a.extras + (in ? (yy / P) * g + (xx / P) : 0)) * pd +
+                           (in ? ((yy % P) * P + (xx % P)) * C : 0);
+        for (int ci = 0; ci < C; ++ci) u[ci][hy][hx] = in ? src[ci] : 0.f;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15, y = ty * 16 + ly, x = tx * 16 + lx;
+    if (y >= S || x >= S) return;
+    float acc[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) acc[co] = co < C ? a.bconv[co] : 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;   // same skipped taps as the untiled kernel
+            for (int ci = 0; ci < C; ++ci) {
+                const float uv = u[ci][ly + dy][lx + dx];
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < C) acc[co] = fmaf(a.wconv[((co * C + ci) * 3 + dy) * 3 + dx], uv, acc[co]);
+            }
+        }
+    const int t = a.st->t;
+    const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
+    const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
+    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+    if (a.x_out && t > 0 && a.noise_mode == 2)
+        zn = philox_normal4(a.st->seed, ((unsigned long long)b * S + y) * S + x, t);   // same pixel id as the untiled kernel
+    for (int co = 0; co < C; ++co) {
+        const long long e = (((long long)b * C + co) * S + y) * S + x;
+        const float eps = acc[co];
+        if (a.eps_out) a.eps_out[e] = eps;
+        if (a.x_out) {
+            float v = cf.c1 * (a.x_in[e] - cf.c2 * eps);
+            if (t > 0) {
+                if (a.noise_mode == 1) v = v + sigma * a.z[e];
+                else if (a.noise_mode == 2) v = v + sigma * zn[co];
             }
             a.x_out[e] = v;
         }
@@ -282,6 +431,19 @@ __global__ void advance_state_kernel(StepState* st) {
 }  // namespace
 
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
+    const int pd_ = a.C * a.P * a.P, nd_ = a.D / 256;
+    if (a.D % 256 == 0) {
+        const int chunks = (a.L + 63) / 64;
+        const long long pad = (long long)a.Mp - (long long)a.B * a.L;
+        const dim3 grid(a.B * chunks + (int)((pad + 63) / 64));
+#define DD_EMB(ND, PD)                                                              \
+    if (nd_ == ND && pd_ == PD) {                                                   \
+        hipLaunchKernelGGL((embed_fast_kernel<ND, PD>), grid, dim3(256), 0, s, a);  \
+        return hipGetLastError();                                                   \
+    }
+        DD_EMB(2, 48) DD_EMB(3, 48) DD_EMB(2, 12) DD_EMB(4, 16)
+#undef DD_EMB
+    }
     const int per_img = (a.L + kEmbedTok - 1) / kEmbedTok;
     const long long pad_rows = (long long)a.Mp - (long long)a.B * a.L;
     const int pad_blocks = (int)((pad_rows + kEmbedTok - 1) / kEmbedTok);
@@ -321,6 +483,11 @@ template hipError_t launch_fill_random<bf16_t>(bf16_t*, long long, unsigned, flo
 template hipError_t launch_fill_random<float>(float*, long long, unsigned, float, hipStream_t);
 
 hipError_t launch_final(const FinalArgs& a, hipStream_t s) {
+    if (a.S >= 16) {
+        const int tiles = (a.S + 15) / 16;
+        hipLaunchKernelGGL(final_tiled_kernel, dim3(a.B * tiles * tiles), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long long npix = (long long)a.B * a.S * a.S;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -11,7 +11,7 @@ for r in rows[:14]:
     print(f"{clean(r['Name'])[:86]:86s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:8.1f} pct={float(r['TotalDurationNs'])/tot*100:5.1f}")
 tr = list(csv.DictReader(open(trace)))
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(tr) if "embed_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(tr) if "embed_" in r["Kernel_Name"]]
 seq = tr[idx[-2]:idx[-1]]
 t0 = int(seq[0]["Start_Timestamp"])
 print(f"== last full step: {len(seq)} kernels, span {(int(seq[-1]['End_Timestamp'])-t0)/1e3:.1f} us, busy {sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in seq)/1e3:.1f} us")
