@@ -676,6 +676,18 @@ int dd_set_gemm_variant(dd_ctx* c, int variant) {
     return DD_OK;
 }
 
+int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out) {
+    if (!q_out || !e_out) return DD_ERR_INVALID;
+    return plan_rows_256(M, N, K, num_cus, q_out, e_out) ? DD_OK : DD_ERR_UNSUPPORTED;
+}
+
+int dd_set_num_cus(dd_ctx* c, int n) {
+    if (!c) return DD_ERR_INVALID;
+    if (n < 8) return fail(c, DD_ERR_INVALID, "need at least 8 CUs");
+    set_gemm_num_cus(n);
+    return DD_OK;
+}
+
 int dd_dev_gemm(dd_ctx* c, int M, int N, int K, int variant, int epilogue, int iters, int check, void* stream,
                 float* ms_out, long long* mismatch_out) {
     if (!c || !ms_out || M < 1 || N < 1 || K < 64 || K % 64 || iters < 1) return DD_ERR_INVALID;

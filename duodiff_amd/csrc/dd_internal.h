@@ -69,6 +69,8 @@ struct GemmArgs {
 template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s);
 template <typename T> hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s);
 void set_gemm_variant(int v);
+void set_gemm_num_cus(int n);
+bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e);
 int get_gemm_variant();
 
 struct EmbedArgs {

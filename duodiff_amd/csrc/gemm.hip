@@ -762,6 +762,16 @@ hipError_t init_gemm_kernels() {
 }
 
 void set_gemm_variant(int v) { g_variant_bf16 = v; }
+bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e) {
+    const int saved = g_num_cus;
+    if (num_cus > 0) g_num_cus = num_cus;
+    Part256 p{};
+    const bool ok = plan256(M, N, K, K, p);
+    g_num_cus = saved;
+    if (ok) { *q = p.q; *e = p.e; }
+    return ok;
+}
+void set_gemm_num_cus(int n) { if (n >= 8) g_num_cus = n / 8 * 8; }
 int get_gemm_variant() { return g_variant_bf16; }
 
 template <typename T>

@@ -156,6 +156,15 @@ int dd_dev_gemm(dd_ctx* ctx, int M, int N, int K, int variant, int epilogue, int
 /* Select the GEMM variant the engine uses for bf16 models (default 0). */
 int dd_set_gemm_variant(dd_ctx* ctx, int variant);
 
+/* Host-only: the row partition the 256x256 GEMM uses for C[M,N] = A[M,K] W[N,K]^T on `num_cus` CUs:
+ * q main tiles of 256 rows + e (<= 8) tail rows per tile; DD_ERR_UNSUPPORTED if the shape falls back
+ * to the generic 128x128 kernel.  Needs no GPU. */
+int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out);
+
+/* Number of CUs the persistent GEMM grids are sized for (default: the device's CU count).  For callers
+ * that run the engine on a CU-masked stream (hipExtStreamCreateWithCUMask). */
+int dd_set_num_cus(dd_ctx* ctx, int num_cus);
+
 /* Per-step timing of the last dd_sample call, measured with hipEvents on its stream:
  * [0] total ms, [1] ms in first-model steps, [2] ms in late-model steps. */
 int dd_last_sample_timing(dd_ctx* ctx, float out3[3]);

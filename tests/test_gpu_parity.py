@@ -261,3 +261,31 @@ def test_ddim_and_other_parametrizations_vs_reference(golden):
     m_s, _ = _uvit(dict(TINY, depth=1), 300, "bf16")
     s, _ = sampler.get_samples(m_s, 2, sampler.predict_previous_postprocessing, 0, 3, 8, 8, num_steps=5, noise="torch_cpu")
     assert s.shape == (2, 8, 8, 3) and np.isfinite(s).all()
+
+
+def test_cli_end_to_end(tmp_path):
+    """The sampler CLI with the reference's flags: YAML configs + checkpoint files (bare state_dict and the
+    trainer's {"model_state_dict": ...} format) -> statistics.txt and samples, DuoDiff switch included."""
+    import subprocess, sys, yaml
+    cfg_s, cfg_f = dict(TINY, depth=1, img_size=16), dict(TINY, depth=3, img_size=16)
+    for name, cfg, seed, wrap in (("s", cfg_s, 1, False), ("f", cfg_f, 2, True)):
+        (tmp_path / f"{name}.yaml").write_text(yaml.safe_dump({"model_params": dict(cfg, classifier_type="x")}))
+        sd = synthetic_state_dict(ModelParams.from_dict(cfg), seed)
+        torch.save({"model_state_dict": sd, "step": 3} if wrap else dict(sd), tmp_path / f"{name}.pth")
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "duodiff_amd.sampler", "--seed", "4", "--checkpoint_path", str(tmp_path / "s.pth"),
+           "--checkpoint_path_late", str(tmp_path / "f.pth"), "--config_path", str(tmp_path / "s.yaml"),
+           "--config_path_late", str(tmp_path / "f.yaml"), "--t_switch", "300", "--batch_size", "3",
+           "--parametrization", "predict_noise", "--output_folder", str(out), "--no_png", "--precision", "fp32",
+           "--noise", "torch_cpu"]
+    r = subprocess.run(cmd, cwd=str(REPO), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (out / "statistics.txt").read_text().startswith("Elapsed time: ")
+    got = np.load(out / "samples.npy")
+    assert got.shape == (3, 16, 16, 3) and got.dtype == np.float32
+    # same run through the oracle: same seeds, same torch CPU noise stream, fp32 -> same images up to drift
+    o_s = _oracle(cfg_s, 1); o_f = _oracle(cfg_f, 2)
+    want, _ = oracle.get_samples(o_s, 3, 4, 3, 16, 16, late_model=o_f, t_switch=300)
+    assert o_s.calls == 300 and o_f.calls == 700
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-3 * scale)

@@ -124,3 +124,36 @@ def test_model_param_validation_through_c_abi():
         ModelParams.from_dict(dict(TINY, img_size=9))
     with pytest.raises(KeyError):
         ModelParams.from_dict({"img_size": 8})
+
+
+def test_gemm_row_partition_covers_every_row_once_and_fills_the_cus():
+    """The 256x256 GEMM's row partition (host arithmetic in libduodiff.so): q*256 main rows + e tail rows per
+    tile cover [0, M) exactly once, and for the BASELINE shapes the tile counts are exact multiples of 256 CUs."""
+    lib = _lib.load()
+    q, e = ctypes.c_int(), ctypes.c_int()
+
+    def plan(M, N, K, cus=256):
+        rc = lib.dd_plan_rows(M, N, K, cus, ctypes.byref(q), ctypes.byref(e))
+        return (q.value, e.value) if rc == 0 else None
+
+    for B, L, D in ((128, 257, 512), (256, 258, 768), (32, 258, 1024), (100, 257, 512), (2, 257, 512)):
+        M = B * L
+        for N, K in ((D, D), (3 * D, D), (4 * D, D), (D, 4 * D), (D, 2 * D)):
+            if N % 256:
+                assert plan(M, N, K) is None
+                continue
+            qq, ee = plan(M, N, K)
+            assert 0 <= ee <= 8 and qq >= 1 and 256 * qq <= M
+            covered = np.zeros(M, np.int32)
+            for t in range(qq):
+                covered[256 * t: 256 * (t + 1)] += 1
+                lo = 256 * qq + t * ee
+                covered[lo: min(M, lo + ee)] += 1
+            assert (covered == 1).all(), (B, L, N, K, qq, ee)
+    # CelebA B=128: 256 / 768 / 1024 tiles -> 1 / 3 / 4 exact rounds on 256 CUs
+    for N, tiles in ((512, 256), (1536, 768), (2048, 1024)):
+        qq, ee = plan(128 * 257, N, 512)
+        assert (qq, ee) == (128, 1) and qq * (N // 256) == tiles
+    # ImageNet-64 B=256, L=258: 2 tail rows per tile instead of 258 M-tiles
+    assert plan(256 * 258, 768, 768) == (256, 2)
+    assert plan(100, 512, 512) is None and plan(1024, 48, 512) is None      # tiny M / narrow N fall back
