@@ -289,3 +289,42 @@ def test_cli_end_to_end(tmp_path):
     assert o_s.calls == 300 and o_f.calls == 700
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(got, want, rtol=0, atol=5e-3 * scale)
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 17, 40])
+def test_ragged_batch_sizes_row_partition(B):
+    """Odd batch sizes drive the GEMM row partition through its edge cases (q = B main tiles, one tail row each;
+    B = 1 is a single 256-row tile + 1 tail row).  bf16 engine vs the oracle on image 0 and B-1, and every image
+    bit-identical to the same image computed alone (B = 1)."""
+    cfg = load_config(REPO / "configs" / "uvit_celeba_3.yaml")
+    m, mp = _uvit(cfg, 1237, "bf16", max_batch=64)
+    orc = _oracle(cfg, 1237)
+    x = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(100 + B))
+    t = torch.full((B,), 321.0)
+    eps = m(x, t).cpu().numpy()
+    assert np.isfinite(eps).all()
+    for i in sorted({0, B - 1}):
+        want = orc(x[i:i + 1].numpy(), np.full((1,), 321.0, np.float32))
+        assert np.abs(eps[i:i + 1] - want).max() <= EPS_TOL["bf16"]
+        alone = m(x[i:i + 1].contiguous(), t[:1]).cpu().numpy()
+        assert np.array_equal(alone, eps[i:i + 1])
+
+
+def test_conditional_model_full_size_labels():
+    """Class-conditional path at full size (ImageNet-64 shallow, L = 258: two tail rows per tile) with distinct labels."""
+    cfg = load_config(REPO / "configs" / "uvit_imagenet64_3.yaml")
+    m, mp = _uvit(cfg, 1239, "bf16", max_batch=8)
+    orc = _oracle(cfg, 1239)
+    B = 6
+    x = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(7))
+    y = torch.tensor([0, 1, 500, 998, 999, 3])
+    t = torch.full((B,), 12.0)
+    eps = m(x, t, y).cpu().numpy()
+    want = orc(x.numpy(), t.numpy(), y.numpy())
+    err = np.abs(eps - want).max()
+    print(f"imagenet64_3 cond B=6: max|eps - oracle| = {err:.3e}")
+    assert err <= EPS_TOL["bf16"]
+    # a different label changes that image's output and only that image's
+    y2 = y.clone(); y2[2] = 501
+    eps2 = m(x, t, y2).cpu().numpy()
+    assert np.array_equal(np.delete(eps, 2, 0), np.delete(eps2, 2, 0)) and not np.array_equal(eps[2], eps2[2])
