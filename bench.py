@@ -176,8 +176,11 @@ def main():
         e2e_tflops = value * flop_img / 1e12 / world
         # dominant kernel: fc1 GEMM + bias + GELU of the full model (2/3 of the block's Linear FLOPs
         # are the MLP pair), timed live with hipEvents on the launch stream
+        # measured IN CONTEXT: hipEvent pairs on the launch stream around every fc1 launch of 20 eager
+        # full-model steps run right after the timed region (same buffers, cache and clock state as the run)
         with torch.cuda.stream(stream):
-            ms, fl = ef.bench_gemm(B, iters=50, stream=stream)
+            ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, stream=stream)
+        fl = 2.0 * B * mp_f.seq_len * 4 * mp_f.embed_dim * mp_f.embed_dim
         ach = fl / (ms * 1e-3) / 1e12
         # HBM bytes of that kernel per launch from the committed two-pass PMC profile (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE; tools/pmc_summary.py) -- rocprofv3 cannot run inside this process
@@ -204,7 +207,7 @@ def main():
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_bytes": (B * mp_f.seq_len * mp_f.embed_dim + 4 * mp_f.embed_dim * mp_f.embed_dim + B * mp_f.seq_len * 4 * mp_f.embed_dim) * 2,
                          "kernel": "gemm256_kernel<EPI_BIAS_GELU> (fc1: bias + exact-erf GELU fused) M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
-                         "ms_per_launch": ms, "flops_per_launch": fl,
+                         "ms_per_launch": ms, "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -47,6 +47,8 @@ SIGNATURES = {
                                  C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dd_sample": (C.c_int, [C.c_void_p, C.POINTER(dd_sample_args), C.c_void_p]),
     "dd_bench_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dd_dev_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                               C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
     "dd_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),

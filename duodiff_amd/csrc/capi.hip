@@ -75,6 +75,10 @@ struct dd_model {
     float* dec = nullptr;
     hipGraphExec_t graph = nullptr;
     GraphKey gkey{};
+    // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
+    bool time_fc1 = false;
+    std::vector<hipEvent_t> fc1_events;   // pairs, grown on demand
+    size_t fc1_used = 0;
 };
 
 namespace {
@@ -236,7 +240,19 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));
         {
             GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hidden};
+            if (m->time_fc1) {
+                while (m->fc1_events.size() < m->fc1_used + 2) {
+                    hipEvent_t e;
+                    DD_HIP(c, hipEventCreate(&e));
+                    m->fc1_events.push_back(e);
+                }
+                DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used], s));
+            }
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s));
+            if (m->time_fc1) {
+                DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used + 1], s));
+                m->fc1_used += 2;
+            }
         }
         {
             // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
@@ -510,6 +526,7 @@ void dd_model_destroy(dd_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     if (m->graph) (void)hipGraphExecDestroy(m->graph);
+    for (hipEvent_t e : m->fc1_events) (void)hipEventDestroy(e);
     if (m->warena) (void)hipFree(m->warena);
     if (m->wsarena) (void)hipFree(m->wsarena);
     delete m;
@@ -633,6 +650,34 @@ int dd_last_sample_timing(dd_ctx* c, float out3[3]) {
     DD_HIP(c, hipEventElapsedTime(&out3[0], c->ev[0], c->ev[2]));
     DD_HIP(c, hipEventElapsedTime(&out3[1], c->ev[0], c->ev[1]));
     DD_HIP(c, hipEventElapsedTime(&out3[2], c->ev[1], c->ev[2]));
+    return DD_OK;
+}
+
+int dd_profile_steps(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
+                     void* stream, float* fc1_ms_out, int* launches_out) {
+    int rc = check_call(c, m, B, y_dev);
+    if (rc) return rc;
+    if (!x_dev || !fc1_ms_out || steps < 1 || t_start > 999 || t_start - steps + 1 < 0) return fail(c, DD_ERR_INVALID, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    m->time_fc1 = true;
+    m->fc1_used = 0;
+    for (int i = 0; i < steps && !rc; ++i) {
+        hipError_t e = launch_set_state(c->st, t_start - i, 12345ull, s);
+        if (e != hipSuccess) { m->time_fc1 = false; return fail_hip(c, e, "set_state"); }
+        rc = enqueue_step(c, m, x_dev, y_dev, DD_NOISE_PHILOX, nullptr, DD_VAR_BETA_TILDE, nullptr, B, s);
+    }
+    m->time_fc1 = false;
+    if (rc) return rc;
+    DD_HIP(c, hipStreamSynchronize(s));
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < m->fc1_used; i += 2) {
+        float ms = 0.f;
+        DD_HIP(c, hipEventElapsedTime(&ms, m->fc1_events[i], m->fc1_events[i + 1]));
+        total += ms;
+    }
+    const int n = (int)(m->fc1_used / 2);
+    *fc1_ms_out = n ? (float)(total / n) : 0.f;
+    if (launches_out) *launches_out = n;
     return DD_OK;
 }
 

@@ -165,6 +165,13 @@ class Model:
                                                    _stream_ptr(stream)))
         return x
 
+    def profile_steps(self, x, t_start=699, steps=10, y=None, stream=None):
+        """Average ms of the fc1 GEMM measured in context (event pairs around every launch of `steps` eager steps)."""
+        ms, n = C.c_float(), C.c_int()
+        self.ctx.check(self.ctx.lib.dd_profile_steps(self.ctx.handle, self.handle, _ptr(x), _ptr(y), int(t_start), int(steps),
+                                                     x.shape[0], _stream_ptr(stream), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def bench_gemm(self, B, iters=20, stream=None):
         ms, fl = C.c_float(), C.c_double()
         self.ctx.check(self.ctx.lib.dd_bench_gemm(self.ctx.handle, self.handle, int(B), int(iters),

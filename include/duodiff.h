@@ -147,6 +147,12 @@ int dd_sample(dd_ctx* ctx, const dd_sample_args* args, void* stream);
  * Returns average milliseconds per launch in *ms_out and the launch's algorithmic FLOPs. */
 int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
                   float* ms_out, double* flops_out);
+/* In-context timing of the dominant kernel: runs `steps` eager sampling steps (t = t_start, t_start-1, ...) in place
+ * on x_dev with a hipEvent pair recorded on `stream` around EVERY fc1 GEMM launch (depth launches per step), and returns
+ * the average milliseconds per launch -- the same thing rocprofv3 --kernel-trace averages for that kernel. */
+int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
+                     void* stream, float* fc1_ms_out, int* launches_out);
+
 /* Development harness: one bf16 GEMM  C[M,N] = A[M,K] W[N,K]^T  on pseudo-random operands with
  * tile/pipeline `variant` and fused `epilogue` (0 store, 1 bias+GELU, 2 bias+residual, 3 bias+set),
  * `iters` timed launches (hipEvents on `stream`).  *mismatch_out = number of output elements that
