@@ -81,6 +81,15 @@ struct dd_model {
     size_t fc1_used = 0;
 };
 
+namespace dd {
+// shared with vae.hip (dd_ctx is defined in this translation unit)
+int ctx_fail(dd_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int ctx_device(dd_ctx* c) { return c->device; }
+}  // namespace dd
+
 namespace {
 
 int fail(dd_ctx* c, int code, const std::string& msg) {

@@ -49,7 +49,8 @@ enum GemmEpilogue {
     EPI_STORE = 0,        // out = T(acc)                                  (qkv)
     EPI_BIAS_GELU = 1,    // out = T(gelu_erf(acc + bias))                 (fc1)
     EPI_BIAS_RESID = 2,   // x += acc + bias ; optional out = T(x)         (proj, fc2)
-    EPI_BIAS_SET = 3      // x  = acc + bias                               (skip_linear)
+    EPI_BIAS_SET = 3,     // x  = acc + bias                               (skip_linear)
+    EPI_BIAS_STORE = 4    // out = T(acc + bias)                           (VAE attention q/k projections)
 };
 
 // C[M,N] = [A | A2][M,K] . W[N,K]^T ; A holds k < K1, A2 holds the rest (concat-free skip GEMM).
@@ -111,6 +112,16 @@ hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, float* out,
                             StepCoef c, int use_noise, long long n, hipStream_t s);
 template <typename T> hipError_t launch_fill_random(T* p, long long n, unsigned seed, float scale, hipStream_t s);
+// ---- KL-VAE decoder bandwidth kernels (vae_kernels.hip)
+hipError_t launch_vae_input(const float* z, const float* w, const float* b, float inv_scale, float* out, int B, int HW, hipStream_t s);
+hipError_t launch_vae_output(const float* in, float* out, int B, int C, int HW, int ldc, hipStream_t s);
+template <typename T> hipError_t launch_im2col3x3(const T* src, T* dst, int B, int H, int W, int C, int up, int Kpad, hipStream_t s);
+template <typename T> hipError_t launch_im2col3x3_c4(const float* src, T* dst, int B, int H, int W, int Kpad, hipStream_t s);
+template <typename T> hipError_t launch_groupnorm(const float* x, float* part, const float* gamma, const float* beta, T* out, int B, int HW, int C, int swish, hipStream_t s);
+int groupnorm_partials(int B, int HW);
+template <typename T> hipError_t launch_softmax_rows(const float* sc, T* p, long long rows, int n, float scale, hipStream_t s);
+template <typename T> hipError_t launch_cast(const float* x, T* out, long long n, hipStream_t s);
+
 hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
                               long long n, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);

@@ -366,7 +366,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     typedef bf16_t T;
     constexpr int TM = 4, TN = 2, NW = 8;
     constexpr int A_BYTES = k256ARows * 128;
-    constexpr int N_EPI_STORES = (EPI == EPI_STORE || EPI == EPI_BIAS_GELU) ? TM * 4 : TM * TN * 4;
+    constexpr int N_EPI_STORES = (EPI == EPI_STORE || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_STORE) ? TM * 4 : TM * TN * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -662,6 +662,7 @@ hipError_t launch_cfg(const GemmArgs<T>& a, int epi, hipStream_t s) {
         case EPI_BIAS_GELU: DD_LAUNCH(EPI_BIAS_GELU)
         case EPI_BIAS_RESID: DD_LAUNCH(EPI_BIAS_RESID)
         case EPI_BIAS_SET: DD_LAUNCH(EPI_BIAS_SET)
+        case EPI_BIAS_STORE: DD_LAUNCH(EPI_BIAS_STORE)
     }
 #undef DD_LAUNCH
     return hipErrorInvalidValue;
@@ -675,7 +676,7 @@ hipError_t init_cfg() {
     if (e == hipSuccess)                                                                                   \
         e = hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, STAGES, E>,                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET)
+    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE)
 #undef DD_ATTR
     return e;
 }
@@ -722,6 +723,7 @@ hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipS
         case EPI_BIAS_GELU: DD_LAUNCH(EPI_BIAS_GELU)
         case EPI_BIAS_RESID: DD_LAUNCH(EPI_BIAS_RESID)
         case EPI_BIAS_SET: DD_LAUNCH(EPI_BIAS_SET)
+        case EPI_BIAS_STORE: DD_LAUNCH(EPI_BIAS_STORE)
     }
 #undef DD_LAUNCH
     return hipErrorInvalidValue;
@@ -752,7 +754,7 @@ hipError_t init_gemm_kernels() {
 #define DD_ATTR(E)                                                                                  \
     if (e == hipSuccess)                                                                            \
         e = hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
-    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET)
+    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE)
 #undef DD_ATTR
     int dev = 0;
     hipDeviceProp_t prop;

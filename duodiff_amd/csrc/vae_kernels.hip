@@ -1,0 +1,236 @@
+// Bandwidth kernels of the KL-VAE decoder (reference models/utils/autoencoder.py:320-449): layout
+// changes, im2col for the 3x3 convolutions (optionally through a nearest-2x upsample), GroupNorm(32)
+// + swish, row softmax of the single-head attention block.  All convolutions themselves run as
+// GEMMs on the MFMA kernels of gemm.hip (NHWC activations: a pixel is a GEMM row).
+#include "dd_internal.h"
+
+namespace dd {
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// z [B,4,H,W] fp32 NCHW -> (1/scale) z -> post_quant_conv 1x1 (4->4, autoencoder.py:486-488) -> NHWC fp32 [B*H*W, 4]
+__global__ void vae_input_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b,
+                                 float inv_scale, float* __restrict__ out, int B, int HW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * HW) return;
+    const int bi = (int)(i / HW), p = (int)(i % HW);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = z[((long long)bi * 4 + c) * HW + p] * inv_scale;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float a = b[o];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a = fmaf(w[o * 4 + c], v[c], a);
+        out[i * 4 + o] = a;
+    }
+}
+
+// NHWC fp32 [B*H*W, ldc] (first C channels) -> NCHW fp32 [B,C,H,W]
+__global__ void vae_output_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW, int ldc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * C * HW) return;
+    const int p = (int)(i % HW), c = (int)((i / HW) % C), bi = (int)(i / ((long long)HW * C));
+    out[i] = in[((long long)bi * HW + p) * ldc + c];
+}
+
+// im2col for a 3x3 / pad 1 convolution over NHWC `src` [B, Hs, Ws, C]; when up == 1 the convolution input is the
+// nearest-2x upsampled image (autoencoder.py:56-59), gathered on the fly.  Row = output pixel, column order
+// (ky, kx, c) (the weights are repacked to match), columns [9C, Kpad) are zero.  8 channels (16 B) per thread.
+template <typename T>
+__global__ void im2col3x3_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int up,
+                                 int Kpad) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cv = C / V;                       // vectors per pixel (C % V == 0), or 1 for the C = 4 input conv
+    const long long per_row = (long long)Kpad / V;
+    const long long total = (long long)B * H * W * per_row;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long row = i / per_row;
+    const int kc = (int)(i % per_row);
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    const int tap = kc / cv, c0 = (kc % cv) * V;
+    if (tap < 9) {
+        const int x = (int)(row % W), y = (int)((row / W) % H), bi = (int)(row / ((long long)W * H));
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int Hs = up ? H / 2 : H, Ws = up ? W / 2 : W;
+            const int ys = up ? yy / 2 : yy, xs = up ? xx / 2 : xx;
+            val = *reinterpret_cast<const f32x4*>(src + (((long long)bi * Hs + ys) * Ws + xs) * C + c0);
+        }
+    }
+    *reinterpret_cast<f32x4*>(dst + row * Kpad + (long long)kc * V) = val;
+}
+
+// conv_in has C = 4 input channels: K = 36, padded to Kpad; scalar gather
+template <typename T>
+__global__ void im2col3x3_c4_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int Kpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * Kpad;
+    if (i >= total) return;
+    const long long row = i / Kpad;
+    const int k = (int)(i % Kpad);
+    float v = 0.f;
+    if (k < 36) {
+        const int tap = k / 4, c = k % 4;
+        const int x = (int)(row % W), y = (int)((row / W) % H), bi = (int)(row / ((long long)W * H));
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = src[(((long long)bi * H + yy) * W + xx) * 4 + c];
+    }
+    dst[i] = Elem<T>::from_f32(v);
+}
+
+// GroupNorm(32 groups, eps 1e-6) statistics: one workgroup per (image, pixel chunk); per-group partial
+// (sum, sum of squares) in fp32 over <= kGnChunk pixels, combined in double by the apply kernel.
+constexpr int kGnChunk = 1024;
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW,
+                                                       int C, int chunks) {
+    __shared__ float sh[4];
+    const int bi = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int cpg = C / 32;
+    const int p0 = ch * kGnChunk, p1 = min(HW, p0 + kGnChunk);
+    // thread -> channel (tid % C) when C <= 256, else each thread walks channels tid, tid+256 ; accumulate per group in LDS
+    __shared__ float gs[32], gq[32];
+    if (threadIdx.x < 32) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f, q = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const float v = x[((long long)bi * HW + p) * C + c];
+            s += v;
+            q = fmaf(v, v, q);
+        }
+        atomicAdd(&gs[c / cpg], s);
+        atomicAdd(&gq[c / cpg], q);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float* o = part + (((long long)bi * chunks + ch) * 32 + threadIdx.x) * 2;
+        o[0] = gs[threadIdx.x];
+        o[1] = gq[threadIdx.x];
+    }
+    (void)sh;
+}
+
+// y = swish?( (x - mean_g) * rstd_g * gamma_c + beta_c ), fp32 in -> T out (the next GEMM's operand type)
+template <typename T>
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, T* __restrict__ out, int HW, int C, int chunks, int swish,
+                                long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int bi = (int)(i / ((long long)HW * C));
+    const int g = c / (C / 32);
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float* o = part + (((long long)bi * chunks + k) * 32 + g) * 2;
+        s += o[0];
+        q += o[1];
+    }
+    const double n = (double)HW * (C / 32);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-6));
+    float v = (x[i] - (float)mean) * rstd * gamma[c] + beta[c];
+    if (swish) v = v / (1.0f + expf(-v));   // x * sigmoid(x)  (autoencoder.py:33-35)
+    out[i] = Elem<T>::from_f32(v);
+}
+
+// softmax over the last dim of S [rows, n] fp32 with a pre-scale; one wave per row; T out
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows,
+                                                           int n, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* sr = s + row * n;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, sr[j] * scale);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) sum += expf(sr[j] * scale - mx);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < n; j += 64) p[row * n + j] = Elem<T>::from_f32(expf(sr[j] * scale - mx) * inv);
+}
+
+// out[i] = T(x[i])   (raw copy of the fp32 stream as a GEMM operand: the 1x1 shortcut convolution)
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Elem<T>::from_f32(x[i]);
+}
+
+inline dim3 grid1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+hipError_t launch_vae_input(const float* z, const float* w, const float* b, float inv_scale, float* out, int B, int HW,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(vae_input_kernel, grid1d((long long)B * HW), dim3(256), 0, s, z, w, b, inv_scale, out, B, HW);
+    return hipGetLastError();
+}
+hipError_t launch_vae_output(const float* in, float* out, int B, int C, int HW, int ldc, hipStream_t s) {
+    hipLaunchKernelGGL(vae_output_kernel, grid1d((long long)B * C * HW), dim3(256), 0, s, in, out, B, C, HW, ldc);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_im2col3x3(const T* src, T* dst, int B, int H, int W, int C, int up, int Kpad, hipStream_t s) {
+    constexpr int V = 16 / (int)sizeof(T);
+    if (C % V || Kpad % V || Kpad < 9 * C) return hipErrorInvalidValue;
+    const long long total = (long long)B * H * W * (Kpad / V);
+    hipLaunchKernelGGL(im2col3x3_kernel<T>, grid1d(total), dim3(256), 0, s, src, dst, B, H, W, C, up, Kpad);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_im2col3x3_c4(const float* src, T* dst, int B, int H, int W, int Kpad, hipStream_t s) {
+    hipLaunchKernelGGL(im2col3x3_c4_kernel<T>, grid1d((long long)B * H * W * Kpad), dim3(256), 0, s, src, dst, B, H, W, Kpad);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_groupnorm(const float* x, float* part, const float* gamma, const float* beta, T* out, int B, int HW, int C,
+                            int swish, hipStream_t s) {
+    if (C % 32) return hipErrorInvalidValue;
+    const int chunks = (HW + kGnChunk - 1) / kGnChunk;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(256), 0, s, x, part, HW, C, chunks);
+    const long long total = (long long)B * HW * C;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, grid1d(total), dim3(256), 0, s, x, part, gamma, beta, out, HW, C, chunks, swish, total);
+    return hipGetLastError();
+}
+int groupnorm_partials(int B, int HW) { return B * ((HW + kGnChunk - 1) / kGnChunk) * 32 * 2; }
+template <typename T>
+hipError_t launch_softmax_rows(const float* sc, T* p, long long rows, int n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, sc, p, rows, n, scale);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_cast(const float* x, T* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(cast_kernel<T>, grid1d(n), dim3(256), 0, s, x, out, n);
+    return hipGetLastError();
+}
+
+#define DD_INST(T)                                                                                                     \
+    template hipError_t launch_im2col3x3<T>(const T*, T*, int, int, int, int, int, int, hipStream_t);                 \
+    template hipError_t launch_im2col3x3_c4<T>(const float*, T*, int, int, int, int, hipStream_t);                    \
+    template hipError_t launch_groupnorm<T>(const float*, float*, const float*, const float*, T*, int, int, int, int, \
+                                            hipStream_t);                                                             \
+    template hipError_t launch_softmax_rows<T>(const float*, T*, long long, int, float, hipStream_t);                 \
+    template hipError_t launch_cast<T>(const float*, T*, long long, hipStream_t);
+DD_INST(bf16_t)
+DD_INST(float)
+#undef DD_INST
+
+}  // namespace dd

@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from .config import ModelParams, load_config
+from .autoencoder import get_autoencoder
 from .engine import Context, sample_loop, schedule_tables
 from .uvit import UViT
 
@@ -130,8 +131,6 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     noise="device": x_T as above, z from the device Philox generator inside the graph-replayed loop.
     num_steps < 1000 runs only the first steps (t = 999 ...), for bounded benchmarks.
     """
-    if autoencoder is not None:
-        raise NotImplementedError("KL-VAE decode is outside the accelerated path (SURVEY section 8f, next-1)")
     device = model.device
     seed_everything(seed)                                                    # sampler.py:99
     x = torch.randn(batch_size, num_channels, sample_height, sample_width).to(device).contiguous()  # :100
@@ -205,6 +204,10 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     else:
         raise ValueError("noise must be 'torch_cpu' or 'device'")
 
+    if autoencoder is not None:                                              # :141-143, :149-150
+        print("Decode the images...")
+        x = autoencoder.decode(x)
+        intermediate = [autoencoder.decode(v) for v in intermediate]
     samples = ((x + 1) / 2).permute(0, 2, 3, 1).contiguous()                 # :145-146
     inter = [((v + 1) / 2).permute(0, 2, 3, 1).contiguous().cpu().numpy() for v in intermediate]
     if return_device_tensor:
@@ -239,6 +242,8 @@ def get_args(argv=None):
     p = ArgumentParser()
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--checkpoint_path", type=str, required=True, help="Path to checkpoint of the model")
+    p.add_argument("--autoencoder_checkpoint_path", type=str, default=None,
+                   help="(engine option) overrides config['autoencoder']['autoencoder_checkpoint_path']")
     p.add_argument("--checkpoint_path_late", type=str, default=None,
                    help="Path to checkpoint of the model to be used in the latest steps")
     p.add_argument("--batch_size", type=int, required=True)
@@ -297,14 +302,16 @@ def main(argv=None):
         y = torch.randint(1, 1001, (args.batch_size,))
         if int(y.max()) >= mp.num_classes:
             raise IndexError("index out of range in self")
-    if "autoencoder" in config:
-        raise NotImplementedError("latent (ImageNet-256) decode needs the KL-VAE, outside the accelerated path")
+    autoencoder = None
+    if "autoencoder" in config:                                              # reference sampler.py:320-325
+        ae_path = args.autoencoder_checkpoint_path or config["autoencoder"]["autoencoder_checkpoint_path"]
+        autoencoder = get_autoencoder(ae_path, precision=args.precision).to(model.device)
 
     tic = time.time()
     samples, inter = get_samples(model=model, batch_size=args.batch_size, postprocessing=post, seed=args.seed,
                                  num_channels=mp.in_chans, sample_height=mp.img_size, sample_width=mp.img_size,
                                  use_ddim=args.use_ddim, ddim_steps=args.ddim_steps, ddim_eta=args.ddim_eta,
-                                 y=y, autoencoder=None, late_model=model_late, t_switch=args.t_switch,
+                                 y=y, autoencoder=autoencoder, late_model=model_late, t_switch=args.t_switch,
                                  timesteps_save=args.timesteps_save, noise=args.noise, use_graph=not args.no_graph)
     tac = time.time()
     dump_statistics(tac - tic, out, args.batch_size)

@@ -141,6 +141,17 @@ typedef struct dd_sample_args {
 } dd_sample_args;
 int dd_sample(dd_ctx* ctx, const dd_sample_args* args, void* stream);
 
+/* ---- KL-VAE decode: autoencoder.decode(x) at sampler.py:141-143 ---------------- */
+/* Replaces FrozenAutoencoderKL.decode (models/utils/autoencoder.py:486-490, Decoder :320-449) for the fixed ddconfig of
+ * get_autoencoder (:503-516).  Parameters are set by the reference state_dict keys ("decoder.*", "post_quant_conv.*";
+ * "encoder.*" / "quant_conv.*" are accepted and ignored).  z_dev [B,4,h,h] fp32 latents -> out_dev [B,3,8h,8h] fp32. */
+typedef struct dd_vae dd_vae;
+int dd_vae_create(dd_ctx* ctx, int max_chunk, int max_latent, dd_vae** out);
+int dd_vae_set_param(dd_vae* v, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int dd_vae_finalize(dd_vae* v, int precision);
+int dd_vae_decode(dd_ctx* ctx, dd_vae* v, const float* z_dev, float* out_dev, int B, int latent_hw, void* stream);
+void dd_vae_destroy(dd_vae* v);
+
 /* ---- measurement support ------------------------------------------------------------ */
 /* Time `iters` back-to-back launches of the engine's dominant kernel (the fc1 GEMM of
  * model m at batch B, fused bias+GELU epilogue) with hipEvents on `stream`.

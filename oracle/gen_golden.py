@@ -18,6 +18,7 @@ Fixtures:
   rng.npz             F6  first values of the torch CPU randn stream after seed_everything(0)
   param_steps.npz         predict_original / predict_previous post-processing (sampler.py:59-79)
   ddim_tiny.npz           get_samples(use_ddim=True) rollouts incl. late-model switch (sampler.py:103-126)
+  vae_decode.npz          FrozenAutoencoderKL.decode (models/utils/autoencoder.py:486-490) on 8x8 and 32x32 latents
   scheduler_tiny.npz      NoiseScheduler.sample with the tiny model (ddpm_core loop)
 """
 import contextlib
@@ -240,6 +241,34 @@ def gen_ddim():
     np.savez(OUT / "ddim_tiny.npz", **out)
 
 
+def gen_vae():
+    """FrozenAutoencoderKL.decode (autoencoder.py:486-490) with the reference's own Decoder / post_quant_conv modules and
+    seeded synthetic weights: a small latent (full output) and the full 32x32 latent (slice + statistics)."""
+    from duodiff_amd.autoencoder import synthetic_vae_state_dict
+    from models.utils.autoencoder import Decoder
+    ddconfig = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                    num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        dec = Decoder(**ddconfig).eval()
+    pq = torch.nn.Conv2d(4, 4, 1).eval()
+    sd = synthetic_vae_state_dict(4321)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
+    pq.load_state_dict({"weight": sd["post_quant_conv.weight"], "bias": sd["post_quant_conv.bias"]})
+    g = torch.Generator().manual_seed(55)
+    out = dict(seed=np.array(4321))
+    with torch.no_grad():
+        z8 = torch.randn(2, 4, 8, 8, generator=g)
+        y8 = dec(pq((1.0 / 0.18215) * z8))
+        out.update(z8=z8.numpy(), y8=y8.numpy())
+        z32 = torch.randn(1, 4, 32, 32, generator=g)
+        y32 = dec(pq((1.0 / 0.18215) * z32)).numpy()
+        out.update(z32=z32.numpy(), y32_slice=y32[:, :, 96:160, 96:160].copy(),
+                   y32_stats=np.array([y32.mean(dtype=np.float64), y32.std(dtype=np.float64), y32.min(), y32.max()]),
+                   y32_checksum=np.array(y32.astype(np.float64).sum()))
+    print("vae golden: y8 std", float(y8.std()), "y32 std", float(y32.std()), flush=True)
+    np.savez(OUT / "vae_decode.npz", **out)
+
+
 def gen_rng():
     ref_seed_everything(0)
     a = torch.randn(64)
@@ -254,7 +283,7 @@ def gen_rng():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "full"]
+    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "vae", "full"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

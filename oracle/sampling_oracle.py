@@ -81,7 +81,7 @@ def scheduler_sample(model, num_steps, data_shape, num_samples, seed, variance_m
 
 
 def get_samples_ddim(model, batch_size, seed, num_channels, sample_height, sample_width, ddim_steps=50, ddim_eta=0.0,
-                     timesteps_save=(), y=None, late_model=None, t_switch=np.inf):
+                     timesteps_save=(), y=None, late_model=None, t_switch=np.inf, autoencoder=None):
     """sampler.py:103-126: the DDIM branch of get_samples, including its two quirks (sigma^2-scaled noise;
     the late model takes over once t < 1000 - t_switch, tested AFTER the step)."""
     tables = sampler_schedule()
@@ -98,6 +98,9 @@ def get_samples_ddim(model, batch_size, seed, num_channels, sample_height, sampl
             model = late_model
         if 1000 - t in timesteps_save:
             inter.append(x)
+    if autoencoder is not None:          # sampler.py:141-143,149-150: `autoencoder` is a callable latents -> images
+        x = autoencoder(x)
+        inter = [autoencoder(v) for v in inter]
     samples = ((x + F32(1)) / F32(2)).astype(F32).transpose(0, 2, 3, 1)
     inter = [((v + F32(1)) / F32(2)).astype(F32).transpose(0, 2, 3, 1) for v in inter]
     return np.ascontiguousarray(samples), inter
