@@ -89,62 +89,91 @@ __global__ void im2col3x3_c4_kernel(const float* __restrict__ src, T* __restrict
     dst[i] = Elem<T>::from_f32(v);
 }
 
-// GroupNorm(32 groups, eps 1e-6) statistics: one workgroup per (image, pixel chunk); per-group partial
-// (sum, sum of squares) in fp32 over <= kGnChunk pixels, combined in double by the apply kernel.
-constexpr int kGnChunk = 1024;
+// GroupNorm(32 groups, eps 1e-6) in three deterministic passes over the NHWC fp32 stream:
+//   gn_stats    one workgroup per (image, chunk of kGnChunk pixels): per-group (sum, sum of squares) partials, fp32,
+//               16-byte loads (a float4 = 4 channels of one group since C/32 >= 4), fixed-order LDS reduction;
+//   gn_finalize one thread per (image, group): partials combined in double -> (mean, rstd);
+//   gn_apply    y = swish?((x - mean) * rstd * gamma + beta) -> T, 16-byte loads.
+constexpr int kGnChunk = 256;
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW,
                                                        int C, int chunks) {
-    __shared__ float sh[4];
+    __shared__ float ss[256], sq[256];
     const int bi = blockIdx.x / chunks, ch = blockIdx.x % chunks;
-    const int cpg = C / 32;
+    const int c4 = C >> 2;                       // float4 columns per pixel: 32, 64 or 128
+    const int rows = 256 / c4;                   // pixels covered per pass
+    const int col = threadIdx.x % c4, r0 = threadIdx.x / c4;
     const int p0 = ch * kGnChunk, p1 = min(HW, p0 + kGnChunk);
-    // thread -> channel (tid % C) when C <= 256, else each thread walks channels tid, tid+256 ; accumulate per group in LDS
-    __shared__ float gs[32], gq[32];
-    if (threadIdx.x < 32) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f, q = 0.f;
-        for (int p = p0; p < p1; ++p) {
-            const float v = x[((long long)bi * HW + p) * C + c];
-            s += v;
-            q = fmaf(v, v, q);
-        }
-        atomicAdd(&gs[c / cpg], s);
-        atomicAdd(&gq[c / cpg], q);
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (long long)bi * HW * C) + col;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + r0; p < p1; p += rows) {
+        const f32x4 v = xp[(long long)p * c4];
+        s += v;
+        q += v * v;
     }
+    ss[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    sq[threadIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 32) {                      // group g owns float4 columns [g*w, (g+1)*w), w = c4/32
+        const int w = c4 >> 5;
+        float a = 0.f, b2 = 0.f;
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < w; ++k) {
+                const int t = r * c4 + threadIdx.x * w + k;
+                a += ss[t];
+                b2 += sq[t];
+            }
         float* o = part + (((long long)bi * chunks + ch) * 32 + threadIdx.x) * 2;
-        o[0] = gs[threadIdx.x];
-        o[1] = gq[threadIdx.x];
+        o[0] = a;
+        o[1] = b2;
     }
-    (void)sh;
 }
 
-// y = swish?( (x - mean_g) * rstd_g * gamma_c + beta_c ), fp32 in -> T out (the next GEMM's operand type)
-template <typename T>
-__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, T* __restrict__ out, int HW, int C, int chunks, int swish,
-                                long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int bi = (int)(i / ((long long)HW * C));
-    const int g = c / (C / 32);
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int n_img_groups, int chunks,
+                                   double count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (image, group)
+    if (i >= n_img_groups) return;
+    const int bi = i >> 5, g = i & 31;
     double s = 0.0, q = 0.0;
     for (int k = 0; k < chunks; ++k) {
         const float* o = part + (((long long)bi * chunks + k) * 32 + g) * 2;
         s += o[0];
         q += o[1];
     }
-    const double n = (double)HW * (C / 32);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
+    const double mean = s / count;
+    double var = q / count - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-6));
-    float v = (x[i] - (float)mean) * rstd * gamma[c] + beta[c];
-    if (swish) v = v / (1.0f + expf(-v));   // x * sigmoid(x)  (autoencoder.py:33-35)
-    out[i] = Elem<T>::from_f32(v);
+    stat[2 * i] = (float)mean;
+    stat[2 * i + 1] = (float)(1.0 / sqrt(var + 1e-6));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ out, int HW, int C, int swish, long long total4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
+    if (i >= total4) return;
+    const int c4 = C >> 2;
+    const int col = (int)(i % c4);
+    const int bi = (int)(i / ((long long)HW * c4));
+    const int g = col / (c4 >> 5);
+    const float mean = stat[2 * (bi * 32 + g)], rstd = stat[2 * (bi * 32 + g) + 1];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[col], be = reinterpret_cast<const f32x4*>(beta)[col];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = (xv[e] - mean) * rstd * ga[e] + be[e];
+        if (swish) t = t / (1.0f + expf(-t));   // x * sigmoid(x)  (autoencoder.py:33-35)
+        v[e] = t;
+    }
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    } else {
+        T o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = Elem<T>::from_f32(v[e]);
+        reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o4);
+    }
 }
 
 // softmax over the last dim of S [rows, n] fp32 with a pre-scale; one wave per row; T out
@@ -203,14 +232,17 @@ hipError_t launch_im2col3x3_c4(const float* src, T* dst, int B, int H, int W, in
 template <typename T>
 hipError_t launch_groupnorm(const float* x, float* part, const float* gamma, const float* beta, T* out, int B, int HW, int C,
                             int swish, hipStream_t s) {
-    if (C % 32) return hipErrorInvalidValue;
+    if (C % 128 || C > 1024) return hipErrorInvalidValue;   // float4 columns: a multiple of 32, at most 256 per block
     const int chunks = (HW + kGnChunk - 1) / kGnChunk;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(256), 0, s, x, part, HW, C, chunks);
-    const long long total = (long long)B * HW * C;
-    hipLaunchKernelGGL(gn_apply_kernel<T>, grid1d(total), dim3(256), 0, s, x, part, gamma, beta, out, HW, C, chunks, swish, total);
+    float* stat = part + (long long)B * chunks * 64;      // (mean, rstd) per (image, group) behind the partials
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * 32 + 255) / 256), dim3(256), 0, s, part, stat, B * 32, chunks,
+                       (double)HW * (C / 32));
+    const long long total4 = (long long)B * HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, grid1d(total4), dim3(256), 0, s, x, stat, gamma, beta, out, HW, C, swish, total4);
     return hipGetLastError();
 }
-int groupnorm_partials(int B, int HW) { return B * ((HW + kGnChunk - 1) / kGnChunk) * 32 * 2; }
+int groupnorm_partials(int B, int HW) { return B * ((HW + kGnChunk - 1) / kGnChunk) * 32 * 2 + B * 64; }
 template <typename T>
 hipError_t launch_softmax_rows(const float* sc, T* p, long long rows, int n, float scale, hipStream_t s) {
     hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, sc, p, rows, n, scale);
