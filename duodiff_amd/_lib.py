@@ -10,6 +10,7 @@ DD_ERR_INVALID, DD_ERR_NOT_FOUND, DD_ERR_STATE, DD_ERR_HIP, DD_ERR_NOMEM, DD_ERR
 DD_PREC_BF16, DD_PREC_FP32 = 0, 1
 DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
 DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
+DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -40,6 +41,11 @@ SIGNATURES = {
     "dd_model_num_params": (C.c_int64, [C.c_void_p]),
     "dd_model_destroy": (None, [C.c_void_p]),
     "dd_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dd_model_enable_early_exit": (C.c_int, [C.c_void_p, C.c_int]),
+    "dd_forward_early_exit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dd_early_exit_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dd_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dd_affine_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p, C.c_int64, C.c_void_p]),

@@ -48,6 +48,8 @@ struct BlockW {
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w, *skip_w;
 };
 
+struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
+
 struct GraphKey {
     const void* x; const void* y; int B, noise, variance;
     bool operator==(const GraphKey& o) const {
@@ -73,6 +75,10 @@ struct dd_model {
     float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
     std::vector<void*> skips;
     float* dec = nullptr;
+    // early-exit baseline (models/early_exit.py:193-268): per-layer output heads + MLP probes; ee_type < 0: plain U-ViT
+    int ee_type = -1, n_probe = 0;
+    std::vector<HeadW> heads;             // head i is applied to the input of block i
+    const float *probe_w = nullptr, *probe_b = nullptr;   // [n_probe, D], [n_probe]
     hipGraphExec_t graph = nullptr;
     GraphKey gkey{};
     // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
@@ -150,6 +156,48 @@ unsigned short host_f2bf(float f) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// ModuleDict key of EarlyExitUViT.matrix -> row of the probe table (early_exit.py:194-204, 219-240); -1: not a key
+int probe_index(const dd_model* m, const std::string& key) {
+    auto num = [](const std::string& v, int& out) {
+        if (v.empty() || v.size() > 6) return false;
+        for (char ch : v) if (ch < '0' || ch > '9') return false;
+        out = std::atoi(v.c_str());
+        return true;
+    };
+    int i = 0, t = 0;
+    switch (m->ee_type) {
+        case DD_EE_MLP_PER_LAYER: return num(key, i) && i < m->cfg.depth ? i : -1;
+        case DD_EE_MLP_PER_TIMESTEP: return num(key, t) && t < 1000 ? t : -1;
+        case DD_EE_MLP_PER_LAYER_PER_TIMESTEP: {
+            const size_t cpos = key.find(", ");
+            if (cpos == std::string::npos) return -1;
+            if (!num(key.substr(0, cpos), i) || !num(key.substr(cpos + 2), t) || i >= m->cfg.depth || t >= 1000) return -1;
+            return t * m->cfg.depth + i;
+        }
+    }
+    return -1;
+}
+std::string probe_key(const dd_model* m, int layer, int t) {
+    switch (m->ee_type) {
+        case DD_EE_MLP_PER_LAYER: return std::to_string(layer);
+        case DD_EE_MLP_PER_TIMESTEP: return std::to_string(t);
+        default: return std::to_string(layer) + ", " + std::to_string(t);
+    }
+}
+std::string head_prefix(const dd_model* m, int layer) {
+    if (layer < m->half_depth) return "in_blocks_heads." + std::to_string(layer) + ".";
+    if (layer == m->half_depth) return "mid_block_head.";
+    return "out_blocks_heads." + std::to_string(layer - m->half_depth - 1) + ".";
+}
+// "in_blocks_heads.<i>.<rest>" / "mid_block_head.<rest>" / "out_blocks_heads.<i>.<rest>" -> layer index, or -1
+int head_index(const dd_model* m, const std::string& name, std::string& rest) {
+    for (int layer = 0; layer < m->cfg.depth; ++layer) {
+        const std::string pre = head_prefix(m, layer);
+        if (name.compare(0, pre.size(), pre) == 0) { rest = name.substr(pre.size()); return layer; }
+    }
+    return -1;
+}
+
 // expected shapes by reference state_dict name (models/uvit.py:228-336)
 bool expected_shape(const dd_model* m, const std::string& name, std::vector<int64_t>& shp) {
     const int64_t D = m->D, C = m->cfg.in_chans, P = m->cfg.patch_size, hid = m->hidden;
@@ -165,6 +213,25 @@ bool expected_shape(const dd_model* m, const std::string& name, std::vector<int6
     if (is("final_layer.bias")) { shp = {C}; return true; }
     std::string rest;
     bool out_blk = false;
+    if (m->ee_type >= 0) {
+        if (name.compare(0, 7, "matrix.") == 0) {               // matrix.<key>.classifier.0.{weight,bias}
+            const size_t e = name.find(".classifier.0.");
+            if (e == std::string::npos || probe_index(m, name.substr(7, e - 7)) < 0) return false;
+            const std::string tail = name.substr(e + 14);
+            if (tail == "weight") { shp = {1, D}; return true; }
+            if (tail == "bias") { shp = {1}; return true; }
+            return false;
+        }
+        std::string hrest;
+        if (head_index(m, name, hrest) >= 0) {
+            if (hrest == "norm.weight" || hrest == "norm.bias") { shp = {D}; return true; }
+            if (hrest == "decoder_pred.weight") { shp = {m->pd, D}; return true; }
+            if (hrest == "decoder_pred.bias") { shp = {m->pd}; return true; }
+            if (hrest == "final_layer.weight") { shp = {C, C, 3, 3}; return true; }
+            if (hrest == "final_layer.bias") { shp = {C}; return true; }
+            return false;
+        }
+    }
     auto strip = [&](const char* pre, bool indexed) -> bool {
         const size_t n = std::strlen(pre);
         if (name.compare(0, n, pre) != 0) return false;
@@ -211,12 +278,28 @@ std::vector<std::string> required_names(const dd_model* m) {
     for (int i = 0; i < m->half_depth; ++i) blk("in_blocks." + std::to_string(i) + ".", false);
     blk("mid_block.", false);
     for (int i = 0; i < m->half_depth; ++i) blk("out_blocks." + std::to_string(i) + ".", true);
+    if (m->ee_type >= 0) {
+        for (int layer = 0; layer < m->cfg.depth; ++layer)
+            for (const char* s : {"norm.weight", "norm.bias", "decoder_pred.weight", "decoder_pred.bias",
+                                  "final_layer.weight", "final_layer.bias"})
+                v.push_back(head_prefix(m, layer) + s);
+        const int nt = m->ee_type == DD_EE_MLP_PER_LAYER ? 1 : 1000, nl = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : m->cfg.depth;
+        for (int t = 0; t < nt; ++t)
+            for (int layer = 0; layer < nl; ++layer) {
+                v.push_back("matrix." + probe_key(m, layer, t) + ".classifier.0.weight");
+                v.push_back("matrix." + probe_key(m, layer, t) + ".classifier.0.bias");
+            }
+    }
     return v;
 }
 
 // ---- the forward: tokens -> blocks -> decoder_pred patches (m->dec) ---------------------------
+// early-exit taps of one forward (EarlyExitUViT.forward, early_exit.py:290-313): cls [depth, B], outs [depth, B, C, S, S]
+struct EeTaps { float* cls; float* outs; int t; };
+
 template <typename T>
-int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s) {
+int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s,
+                 const EeTaps* ee = nullptr) {
     dd_ctx* c = m->ctx;
     const int D = m->D, L = m->L, M = B * L;
     const int Mp = round_up(M, 256);
@@ -230,6 +313,21 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
+        if (ee) {
+            // output head and uncertainty probe on the INPUT of block bi (for out-blocks: before skip_linear, as the
+            // reference taps x before blk(x, skip)); both read the fp32 residual stream
+            const HeadW& hd = m->heads[bi];
+            float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
+            DD_HIP(c, launch_layernorm<float>(m->x, hd.ng, hd.nb, hf, M, D, s));
+            GemmArgs<float> g{hf, nullptr, hd.wdec, hd.bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
+            DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s));
+            const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+            FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
+                         c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
+            DD_HIP(c, launch_final(fa, s));
+            const int pi = m->ee_type == DD_EE_MLP_PER_LAYER ? bi : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? ee->t : ee->t * nb + bi;
+            DD_HIP(c, launch_ee_probe(m->x, m->probe_w + (long long)pi * D, m->probe_b + pi, ee->cls + (long long)bi * B, B, L, D, s));
+        }
         if (is_out) {
             const int oi = bi - m->half_depth - 1;
             const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
@@ -282,9 +380,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     return DD_OK;
 }
 
-int run_model(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s) {
-    return m->prec == DD_PREC_BF16 ? run_backbone<bf16_t>(m, x_img, t_vec, y_dev, B, s)
-                                   : run_backbone<float>(m, x_img, t_vec, y_dev, B, s);
+int run_model(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s,
+              const EeTaps* ee = nullptr) {
+    return m->prec == DD_PREC_BF16 ? run_backbone<bf16_t>(m, x_img, t_vec, y_dev, B, s, ee)
+                                   : run_backbone<float>(m, x_img, t_vec, y_dev, B, s, ee);
 }
 
 int check_call(dd_ctx* c, dd_model* m, int B, const int64_t* y_dev) {
@@ -495,6 +594,32 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
+    struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv; };
+    std::vector<HeadOff> hoffs;
+    size_t o_pw = 0, o_pb = 0;
+    if (m->ee_type >= 0) {
+        for (int layer = 0; layer < m->cfg.depth; ++layer) {
+            const std::string p = head_prefix(m, layer);
+            HeadOff o{};
+            o.ng = put_f32(P(p + "norm.weight").data(), D); o.nb = put_f32(P(p + "norm.bias").data(), D);
+            o.wdec = put_f32(P(p + "decoder_pred.weight").data(), (size_t)m->pd * D); o.bdec = put_f32(P(p + "decoder_pred.bias").data(), m->pd);
+            o.wconv = put_f32(P(p + "final_layer.weight").data(), P(p + "final_layer.weight").size());
+            o.bconv = put_f32(P(p + "final_layer.bias").data(), m->cfg.in_chans);
+            hoffs.push_back(o);
+        }
+        const int nt = m->ee_type == DD_EE_MLP_PER_LAYER ? 1 : 1000, nl = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : m->cfg.depth;
+        m->n_probe = nt * nl;
+        std::vector<float> pw((size_t)m->n_probe * D), pb(m->n_probe);
+        for (int t = 0; t < nt; ++t)
+            for (int layer = 0; layer < nl; ++layer) {
+                const std::string key = probe_key(m, layer, t);
+                const int row = probe_index(m, key);
+                std::memcpy(&pw[(size_t)row * D], P("matrix." + key + ".classifier.0.weight").data(), (size_t)D * 4);
+                pb[row] = P("matrix." + key + ".classifier.0.bias")[0];
+            }
+        o_pw = put_f32(pw.data(), pw.size());
+        o_pb = put_f32(pb.data(), pb.size());
+    }
     align();
 
     DD_HIP(c, hipMalloc((void**)&m->warena, host.size()));
@@ -508,6 +633,8 @@ int dd_model_finalize(dd_model* m, int precision) {
         m->blocks.push_back(w);
     }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
+    for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv)});
+    if (m->ee_type >= 0) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
     m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdec = F(o_wdec); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
 
     // ---- activation workspace (HBM-resident for the life of the model)
@@ -553,6 +680,46 @@ int dd_forward(dd_ctx* c, dd_model* m, const float* x_dev, float t, const float*
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
     DD_HIP(c, launch_final(fa, s));
+    return DD_OK;
+}
+
+int dd_model_enable_early_exit(dd_model* m, int classifier_type) {
+    if (!m) return DD_ERR_INVALID;
+    dd_ctx* c = m->ctx;
+    if (m->finalized || !m->params.empty()) return fail(c, DD_ERR_STATE, "enable early exit before any parameter is set");
+    if (classifier_type < DD_EE_MLP_PER_LAYER || classifier_type > DD_EE_MLP_PER_LAYER_PER_TIMESTEP)
+        return fail(c, DD_ERR_UNSUPPORTED, "classifier type: only the MLP probes are implemented");
+    m->ee_type = classifier_type;
+    return DD_OK;
+}
+
+int dd_forward_early_exit(dd_ctx* c, dd_model* m, const float* x_dev, float t, const float* t_dev, const int64_t* y_dev,
+                          float* eps_dev, float* classifier_dev, float* outputs_dev, int B, void* stream) {
+    int rc = check_call(c, m, B, y_dev);
+    if (rc) return rc;
+    if (m->ee_type < 0) return fail(c, DD_ERR_STATE, "model was not created with dd_model_enable_early_exit");
+    if (!x_dev || !eps_dev || !classifier_dev || !outputs_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    const int ti = (int)t;                                   // t = int(timesteps[0]) (early_exit.py:271)
+    if (m->ee_type != DD_EE_MLP_PER_LAYER && (ti < 0 || ti > 999)) return fail(c, DD_ERR_NOT_FOUND, "no probe for this timestep (KeyError in the reference)");
+    hipStream_t s = (hipStream_t)stream;
+    DD_HIP(c, launch_set_state_float(c->st, t, s));
+    const EeTaps ee{classifier_dev, outputs_dev, ti};
+    rc = run_model(m, x_dev, t_dev, y_dev, B, s, &ee);
+    if (rc) return rc;
+    FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
+    DD_HIP(c, launch_final(fa, s));
+    return DD_OK;
+}
+
+int dd_early_exit_select(dd_ctx* c, const float* outputs_dev, const float* eps_dev, const float* classifier_dev,
+                         float threshold, int depth, int B, int64_t chw, float* model_output_dev, int32_t* indices_dev,
+                         float* err_mean_dev, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    if (!outputs_dev || !eps_dev || !classifier_dev || !model_output_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (depth < 1 || B < 1 || chw < 1) return fail(c, DD_ERR_INVALID, "depth, B and chw must be positive");
+    DD_HIP(c, launch_ee_select(outputs_dev, eps_dev, classifier_dev, threshold, depth, B, (long long)chw, model_output_dev,
+                               indices_dev, err_mean_dev, (hipStream_t)stream));
     return DD_OK;
 }
 

@@ -124,6 +124,9 @@ template <typename T> hipError_t launch_cast(const float* x, T* out, long long n
 
 hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
                               long long n, hipStream_t s);
+hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s);
+hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
+                            float* mo, int* idx, float* err_mean, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
 hipError_t launch_advance_state(StepState* st, hipStream_t s);

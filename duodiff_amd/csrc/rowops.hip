@@ -428,6 +428,54 @@ __global__ void advance_state_kernel(StepState* st) {
     st->t_model = (float)t;
 }
 
+// ---- early-exit baseline (reference models/early_exit.py, eesampler.py) --------------------------------------
+// MLPProbe (early_exit.py:31-37): u[b] = mean over the L tokens of sigmoid(x[b,l,:] . w + bias).  One workgroup per
+// image, one wave per token row (coalesced 256 B segments), fixed-order reductions (deterministic per image).
+__global__ void __launch_bounds__(256) ee_probe_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int L,
+                                                       int D) {
+    __shared__ float part[4];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float bv = bias[0];
+    float acc = 0.f;
+    for (int l = wave; l < L; l += 4) {
+        const float* xr = x + ((long long)b * L + l) * D;
+        float d = 0.f;
+        for (int k = lane; k < D; k += 64) d = fmaf(xr[k], w[k], d);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        acc += 1.0f / (1.0f + expf(-(d + bv)));
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)L;
+}
+
+// eesampler.py:61-67: idx[b] = first layer i in [0, depth] with c[i][b] <= threshold, where c[depth][b] = 0 closes the
+// list (torch.argmax of an all-False column is 0); model_output[b] = (outputs ++ [eps])[idx[b]][b].
+__global__ void ee_select_kernel(const float* __restrict__ outs, const float* __restrict__ eps, const float* __restrict__ cls,
+                                 float thr, int depth, int B, long long chw, float* __restrict__ mo, int* __restrict__ idx_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * chw) return;
+    const int b = (int)(i / chw);
+    int idx = -1;
+    for (int k = 0; k < depth && idx < 0; ++k)
+        if (cls[(long long)k * B + b] <= thr) idx = k;
+    if (idx < 0) idx = (0.0f <= thr) ? depth : 0;
+    mo[i] = idx == depth ? eps[i] : outs[(long long)idx * B * chw + i];
+    if (idx_out && i == (long long)b * chw) idx_out[b] = idx;
+}
+
+// eesampler.py:70: per-layer mean over the batch of the predicted errors (logging)
+__global__ void __launch_bounds__(64) ee_batch_mean_kernel(const float* __restrict__ cls, float* __restrict__ err, int B) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    float a = 0.f;
+    for (int b = lane; b < B; b += 64) a += cls[(long long)k * B + b];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) err[k] = a / (float)B;
+}
+
 }  // namespace
 
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
@@ -504,6 +552,18 @@ hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, fl
 hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
                               long long n, hipStream_t s) {
     hipLaunchKernelGGL(affine_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, m, z, out, a, b, c, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ee_probe_kernel, dim3(B), dim3(256), 0, s, x, w, bias, out, L, D);
+    return hipGetLastError();
+}
+hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
+                            float* mo, int* idx, float* err_mean, hipStream_t s) {
+    const long long n = (long long)B * chw;
+    hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx);
+    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B);
     return hipGetLastError();
 }
 

@@ -75,6 +75,17 @@ class Context:
                                          _ptr(out), x.numel(), _stream_ptr(stream)))
         return out
 
+    def early_exit_select(self, outputs, eps, classifier_outputs, threshold, stream=None):
+        """eesampler.py:61-71 on device tensors -> (model_output [B,...], indices int32 [B], batch-mean errors [depth])."""
+        depth, B = classifier_outputs.shape
+        mo = torch.empty_like(eps)
+        idx = torch.empty(B, device=eps.device, dtype=torch.int32)
+        err = torch.empty(depth, device=eps.device, dtype=torch.float32)
+        self.check(self.lib.dd_early_exit_select(self.handle, _ptr(outputs), _ptr(eps), _ptr(classifier_outputs),
+                                                 float(threshold), depth, B, eps.numel() // max(B, 1), _ptr(mo), _ptr(idx),
+                                                 _ptr(err), _stream_ptr(stream)))
+        return mo, idx, err
+
     def affine_step(self, x, m, z, a, b, c, out=None, stream=None):
         """out = a*x + b*m + c*z on device tensors (z may be None)."""
         out = torch.empty_like(x) if out is None else out
@@ -134,6 +145,23 @@ class Model:
         self.handle = h
         self.finalized = False
         self.precision = None
+
+    def enable_early_exit(self, classifier_type="mlp_probe_per_layer"):
+        kinds = {"mlp_probe_per_layer": L.DD_EE_MLP_PER_LAYER, "mlp_probe_per_timestep": L.DD_EE_MLP_PER_TIMESTEP,
+                 "mlp_probe_per_layer_per_timestep": L.DD_EE_MLP_PER_LAYER_PER_TIMESTEP}
+        if classifier_type not in kinds:
+            raise NotImplementedError(f"classifier_type {classifier_type!r}: only the MLP probes are implemented")
+        self.ctx.check(self.ctx.lib.dd_model_enable_early_exit(self.handle, kinds[classifier_type]))
+
+    def forward_early_exit(self, x, t, y=None, t_vec=None, stream=None):
+        """(eps [B,C,S,S], classifier_outputs [depth,B], outputs [depth,B,C,S,S]) of EarlyExitUViT.forward."""
+        B, depth = x.shape[0], self.mp.depth
+        eps = torch.empty_like(x)
+        cls = torch.empty(depth, B, device=x.device, dtype=torch.float32)
+        outs = torch.empty((depth,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+        self.ctx.check(self.ctx.lib.dd_forward_early_exit(self.ctx.handle, self.handle, _ptr(x), float(t), _ptr(t_vec), _ptr(y),
+                                                          _ptr(eps), _ptr(cls), _ptr(outs), B, _stream_ptr(stream)))
+        return eps, cls, outs
 
     def set_param(self, name, tensor):
         t = tensor.detach().to("cpu", torch.float32).contiguous()

@@ -86,3 +86,66 @@ def synthetic_state_dict(mp: ModelParams, seed: int = 1234, weight_std: float = 
             t = weight_std * torch.randn(shp, generator=g)
         sd[name] = t.to(torch.float32).contiguous()
     return sd
+
+
+# ---- early-exit baseline (reference models/early_exit.py:193-268) ------------------------------
+EE_CLASSIFIER_TYPES = ("mlp_probe_per_layer", "mlp_probe_per_timestep", "mlp_probe_per_layer_per_timestep")
+
+
+def ee_probe_keys(mp: ModelParams, classifier_type: str):
+    """ModuleDict keys of ``EarlyExitUViT.matrix`` (early_exit.py:219-240)."""
+    if classifier_type == "mlp_probe_per_layer":
+        return [f"{i}" for i in range(mp.depth)]
+    if classifier_type == "mlp_probe_per_timestep":
+        return [f"{t}" for t in range(1000)]
+    if classifier_type == "mlp_probe_per_layer_per_timestep":
+        return [f"{i}, {t}" for t in range(1000) for i in range(mp.depth)]
+    raise NotImplementedError(f"classifier_type {classifier_type!r}: only the MLP probes are implemented "
+                              f"(every shipped deediff_*.yaml uses mlp_probe_per_layer)")
+
+
+def ee_head_prefixes(mp: ModelParams):
+    """Output heads in layer order: the head applied BEFORE block i (early_exit.py:290-313)."""
+    half = mp.depth // 2
+    return ([f"in_blocks_heads.{i}." for i in range(half)] + ["mid_block_head."] +
+            [f"out_blocks_heads.{i}." for i in range(half)])
+
+
+def ee_param_shapes(mp: ModelParams, classifier_type: str = "mlp_probe_per_layer") -> "OrderedDict[str, tuple]":
+    """state_dict schema of the reference ``EarlyExitUViT``: ``uvit.*`` + probes + per-layer output heads."""
+    D, C = mp.embed_dim, mp.in_chans
+    s = OrderedDict(("uvit." + k, v) for k, v in param_shapes(mp).items())
+    for key in ee_probe_keys(mp, classifier_type):
+        s[f"matrix.{key}.classifier.0.weight"] = (1, D)
+        s[f"matrix.{key}.classifier.0.bias"] = (1,)
+    for p in ee_head_prefixes(mp):
+        s[p + "norm.weight"] = (D,)
+        s[p + "norm.bias"] = (D,)
+        s[p + "decoder_pred.weight"] = (mp.patch_dim, D)
+        s[p + "decoder_pred.bias"] = (mp.patch_dim,)
+        s[p + "final_layer.weight"] = (C, C, 3, 3)
+        s[p + "final_layer.bias"] = (C,)
+    return s
+
+
+def synthetic_ee_state_dict(mp: ModelParams, seed: int = 1234, classifier_type: str = "mlp_probe_per_layer"):
+    """Seeded EarlyExitUViT weights: the U-ViT part is ``synthetic_state_dict(mp, seed)``; probes get
+    w ~ N(0, (4/sqrt(D))^2), b ~ N(0, 1) so that the uncertainty estimates spread over (0, 1); heads as the U-ViT head."""
+    sd = OrderedDict(("uvit." + k, v) for k, v in synthetic_state_dict(mp, seed).items())
+    g = torch.Generator(device="cpu").manual_seed(int(seed) + 7919)
+    D = mp.embed_dim
+    for name, shp in ee_param_shapes(mp, classifier_type).items():
+        if name.startswith("uvit."):
+            continue
+        if name.startswith("matrix."):
+            t = (4.0 / D ** 0.5) * torch.randn(shp, generator=g) if name.endswith("weight") else torch.randn(shp, generator=g)
+        elif name.endswith("norm.weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(shp, generator=g)
+        elif "final_layer" in name:
+            t = 0.2 * torch.randn(shp, generator=g)
+        else:
+            t = 0.02 * torch.randn(shp, generator=g)
+        sd[name] = t.to(torch.float32).contiguous()
+    return sd

@@ -104,6 +104,27 @@ void dd_model_destroy(dd_model* m);
 int dd_forward(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const float* t_dev,
                const int64_t* y_dev, float* eps_dev, int B, void* stream);
 
+/* ---- early-exit baseline: EarlyExitUViT (models/early_exit.py:193-324) + eesampler.py ---- */
+/* Which uncertainty probe the model carries (early_exit.py:194-204).  attention_probe is not implemented
+ * (no shipped config uses it). */
+enum { DD_EE_MLP_PER_LAYER = 0, DD_EE_MLP_PER_TIMESTEP = 1, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 2 };
+/* Call right after dd_model_create.  dd_model_set_param then also takes the EarlyExitUViT state_dict names
+ * (U-ViT names WITHOUT the "uvit." prefix, plus "matrix.<key>.classifier.0.{weight,bias}",
+ * "in_blocks_heads.<i>.*", "mid_block_head.*", "out_blocks_heads.<i>.*") and finalize requires all of them. */
+int dd_model_enable_early_exit(dd_model* m, int classifier_type);
+/* (eps, classifier_outputs, outputs) = EarlyExitUViT.forward(x, timesteps, y) (early_exit.py:270-320).
+ * t = int(timesteps[0]) selects the probes; t_dev as in dd_forward.  classifier_dev [depth, B] fp32: the MLPProbe
+ * of the input of every block; outputs_dev [depth, B, C, S, S] fp32: the OutputHead of the same inputs. */
+int dd_forward_early_exit(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const float* t_dev,
+                          const int64_t* y_dev, float* eps_dev, float* classifier_dev, float* outputs_dev,
+                          int B, void* stream);
+/* eesampler.py:61-71: per sample the first layer whose predicted error is <= threshold (the final output closes the
+ * list with error 0; an all-False column selects layer 0 like torch.argmax) -> model_output_dev [B, chw],
+ * indices_dev [B] int32 (or NULL), err_mean_dev [depth] = batch mean of classifier_dev rows (or NULL). */
+int dd_early_exit_select(dd_ctx* ctx, const float* outputs_dev, const float* eps_dev, const float* classifier_dev,
+                         float threshold, int depth, int B, int64_t chw, float* model_output_dev,
+                         int32_t* indices_dev, float* err_mean_dev, void* stream);
+
 /* ---- x = postprocessing(eps, x, t)  (sampler.py:47-56 == ddpm_core.py:190-193) ------ */
 /* n = number of elements.  z_dev may be NULL (treated as 0); it is ignored when t == 0. */
 int dd_ddpm_step(dd_ctx* ctx, const float* x_dev, const float* eps_dev, const float* z_dev,

@@ -32,4 +32,5 @@ from .uvit_oracle import (  # noqa: F401
 )
 from .uvit_oracle_torch import UViTTorchOracle  # noqa: F401
 from .vae_oracle import vae_decode  # noqa: F401
+from .early_exit_oracle import EarlyExitOracle, early_exit_select, ee_get_samples  # noqa: F401
 from .sampling_oracle import get_samples, get_samples_ddim, scheduler_sample, seed_everything  # noqa: F401

@@ -19,6 +19,7 @@ Fixtures:
   param_steps.npz         predict_original / predict_previous post-processing (sampler.py:59-79)
   ddim_tiny.npz           get_samples(use_ddim=True) rollouts incl. late-model switch (sampler.py:103-126)
   vae_decode.npz          FrozenAutoencoderKL.decode (models/utils/autoencoder.py:486-490) on 8x8 and 32x32 latents
+  ee_forward.npz / ee_rollout.npz   EarlyExitUViT.forward (models/early_exit.py:270-320), eesampler.get_samples (:40-89)
   scheduler_tiny.npz      NoiseScheduler.sample with the tiny model (ddpm_core loop)
 """
 import contextlib
@@ -269,6 +270,52 @@ def gen_vae():
     np.savez(OUT / "vae_decode.npz", **out)
 
 
+def gen_ee():
+    """Early-exit baseline: EarlyExitUViT.forward (models/early_exit.py:270-320) for the three MLP probe types, and the
+    eesampler.get_samples rollout (eesampler.py:40-89), tiny model, reference code on CPU."""
+    from duodiff_amd.weights import synthetic_ee_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        import eesampler as ref_ee
+        from models.early_exit import EarlyExitUViT as RefEE
+
+    def build(cfg, seed, ctype):
+        mp = ModelParams.from_dict(cfg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = RefEE(RefUViT(**mp.as_dict()), ctype)
+        m.load_state_dict(synthetic_ee_state_dict(mp, seed, ctype), strict=True)
+        return m.eval(), mp
+
+    out = {}
+    g = torch.Generator().manual_seed(808)
+    cases = [("layer", dict(TINY), "mlp_probe_per_layer", 41, 640.0),
+             ("timestep", dict(TINY), "mlp_probe_per_timestep", 42, 17.0),
+             ("layer_timestep_cond", dict(TINY, num_classes=10), "mlp_probe_per_layer_per_timestep", 43, 999.0)]
+    for tag, cfg, ctype, seed, t in cases:
+        m, mp = build(cfg, seed, ctype)
+        x = torch.randn(3, 3, 8, 8, generator=g)
+        y = torch.tensor([1, 9, 4]) if cfg["num_classes"] > 0 else None
+        with torch.no_grad():
+            eps, cls, outs = m(x, t * torch.ones(3), y)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_t": np.array(t, np.float32), f"{tag}_seed": np.array(seed),
+                    f"{tag}_eps": eps.numpy(), f"{tag}_cls": torch.stack(cls).numpy(), f"{tag}_outs": torch.stack(outs).numpy()})
+        if y is not None:
+            out[f"{tag}_y"] = y.numpy()
+        print(f"ee forward {tag}: cls", torch.stack(cls).numpy().round(3).tolist(), flush=True)
+    np.savez(OUT / "ee_forward.npz", **out)
+
+    m, mp = build(dict(TINY), 41, "mlp_probe_per_layer")
+    roll = dict(seed_model=np.array(41))
+    for thr in (0.45, 0.39, -1.0):
+        with contextlib.redirect_stderr(io.StringIO()):
+            samples, err, ind = ref_ee.get_samples(m, 3, 5, 3, 8, 8, thr, mp.depth)
+        tag = f"thr{int(round(abs(thr) * 100))}"
+        roll.update({f"{tag}_samples": samples, f"{tag}_err": err.numpy(), f"{tag}_ind": ind.numpy(),
+                     f"{tag}_threshold": np.array(thr, np.float32)})
+        print(f"ee rollout thr={thr}: exit histogram", np.bincount(ind.numpy().astype(int).ravel(), minlength=4).tolist(),
+              "finite", bool(np.isfinite(samples).all()), flush=True)
+    np.savez(OUT / "ee_rollout.npz", **roll)
+
+
 def gen_rng():
     ref_seed_everything(0)
     a = torch.randn(64)
@@ -283,7 +330,7 @@ def gen_rng():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "vae", "full"]
+    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "vae", "ee", "full"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()
