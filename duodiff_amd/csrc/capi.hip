@@ -62,7 +62,7 @@ struct GraphKey {
 struct dd_model {
     dd_ctx* ctx = nullptr;
     dd_config cfg{};
-    int D = 0, L = 0, N = 0, extras = 0, pd = 0, pdp = 0, H = 0, hidden = 0, half_depth = 0, Mp_max = 0;
+    int D = 0, L = 0, N = 0, extras = 0, pd = 0, pdp = 0, H = 0, hidden = 0, hid_ld = 0, half_depth = 0, Mp_max = 0;
     std::map<std::string, HostParam> params;
     bool finalized = false;
     int prec = DD_PREC_BF16;
@@ -346,7 +346,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         }
         DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));
         {
-            GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hidden};
+            GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hid_ld};
             if (m->time_fc1) {
                 while (m->fc1_events.size() < m->fc1_used + 2) {
                     hipEvent_t e;
@@ -366,7 +366,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
             T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
             GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
-                          m->hidden, 0, D};
+                          m->hid_ld, m->hid_ld, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
         }
     }
@@ -498,6 +498,7 @@ int dd_model_create(dd_ctx* c, const dd_config* cfg, dd_model** out) {
     m->pd = g.patch_size * g.patch_size * g.in_chans;
     m->pdp = round_up(m->pd, 8);
     m->hidden = g.embed_dim * (g.mlp_ratio > 0 ? g.mlp_ratio : 4);
+    m->hid_ld = m->hidden;   // row stride of the MLP hidden activation (a +64 pad against power-of-two strides measured no gain)
     m->half_depth = g.depth / 2;
     m->Mp_max = round_up(g.max_batch * m->L, 256);
     if (m->L > 288) { delete m; return fail(c, DD_ERR_UNSUPPORTED, "sequence length must be <= 288 tokens"); }
@@ -642,7 +643,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(Mp * 3 * D * es);
-    const size_t o_hid = take(Mp * hid * es), o_xb = take(Mp * D * es);
+    const size_t o_hid = take(Mp * (size_t)m->hid_ld * es), o_xb = take(Mp * D * es);
     std::vector<size_t> o_sk;
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
     const size_t o_dec = take(Mp * m->pd * 4);
@@ -867,11 +868,11 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
     auto once = [&]() -> hipError_t {
         if (m->prec == DD_PREC_BF16) {
             GemmArgs<bf16_t> g{(const bf16_t*)m->h, nullptr, (const bf16_t*)w.fc1_w, w.fc1_b, nullptr, (bf16_t*)m->hid,
-                               M, m->hidden, D, D, D, 0, m->hidden};
+                               M, m->hidden, D, D, D, 0, m->hid_ld};
             return launch_gemm<bf16_t>(g, EPI_BIAS_GELU, s);
         }
         GemmArgs<float> g{(const float*)m->h, nullptr, (const float*)w.fc1_w, w.fc1_b, nullptr, (float*)m->hid,
-                          M, m->hidden, D, D, D, 0, m->hidden};
+                          M, m->hidden, D, D, D, 0, m->hid_ld};
         return launch_gemm<float>(g, EPI_BIAS_GELU, s);
     };
     DD_HIP(c, once());
@@ -892,7 +893,7 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
 
 int dd_set_gemm_variant(dd_ctx* c, int variant) {
     if (!c) return DD_ERR_INVALID;
-    if (variant < 0 || variant > 8) return fail(c, DD_ERR_INVALID, "unknown GEMM variant");
+    if (variant < 0 || (variant > 8 && variant != 14)) return fail(c, DD_ERR_INVALID, "unknown GEMM variant");
     set_gemm_variant(variant);
     return DD_OK;
 }
@@ -981,6 +982,15 @@ int dd_dev_gemm(dd_ctx* c, int M, int N, int K, int variant, int epilogue, int i
     float ms = 0.f;
     DD_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if ((variant & 0xff) == 14) {   // development: cycle stamps of workgroup 0, waves 0 and 4 (gemm256_kernel<.., DEV=1>)
+        unsigned long long st[128];
+        DD_TRY(hipMemcpy(st, x1, sizeof(st), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "stamps wave %d:", w * 4);
+            for (int i = 1; i < 30; ++i) fprintf(stderr, " %lld", (long long)(st[w * 64 + i] - st[w * 64 + i - 1]));
+            fprintf(stderr, "\n");
+        }
+    }
 #undef DD_TRY
     cleanup();
     *ms_out = ms / (float)iters;

@@ -79,23 +79,24 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
         for (int e = 0; e < 4; ++e) r[e] = gelu_erf<T>(v[e]);
         return r;
     } else {
-        // bf16 mode: erf from Abramowitz-Stegun 7.1.25, erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) e^{-z^2},
-        // t = 1/(1 + 0.47047 z), |error| <= 2.5e-5 -- two orders below the bf16 rounding of the
-        // output -- with z = |v|/sqrt2 folded into the constants.  7 VALU issue slots per element:
-        //   gelu(v) = 0.5 (v + |v|) - |v| * (0.5 poly(t)) * exp2(-|v|^2 log2(e)/2)
-        const f32x4 u = __builtin_elementwise_abs(v);
-        const f32x4 d = u * (0.47047f * 0.70710678118654752440f) + 1.0f;
-        f32x4 t, e;
+        // bf16 mode: the result is rounded to bf16 (2^-9 relative), so erf(v/sqrt2) comes from an odd minimax polynomial
+        // s*P(s^2) on the clamped argument s = med3(v, -3.8, 3.8) (|error| <= 1.3e-4; beyond the clamp erf is 1 - 1.4e-4):
+        // gelu absolute error <= 2.4e-4, a quarter of the bf16 rounding of typical outputs.  No transcendental at all:
+        // 4 v_med3 + 20 packed-fp32 ops per register quad.  The Abramowitz-Stegun 7.1.25 form used before (v_rcp + v_exp,
+        // quarter rate) cost 2.4x more VALU time and made the fc1 epilogue ~29 us of pure VALU work per launch.
+        f32x4 sc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(d[i]);
-        f32x4 q = t * (0.5f * 0.7478556f) + (0.5f * -0.0958798f);
-        q = q * t + (0.5f * 0.3480242f);
-        q = q * t;
-        const f32x4 a2 = (u * u) * (-0.5f * 1.4426950408889634f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a2[i]);
-        const f32x4 w = u * (q * e);
-        return (v + u) * 0.5f - w;
+        for (int i = 0; i < 4; ++i) sc[i] = __builtin_amdgcn_fmed3f(v[i], -3.8f, 3.8f);
+        const f32x4 s2 = sc * sc;
+        f32x4 p = s2 * 7.331517960e-08f + -4.544908101e-06f;
+        p = p * s2 + 1.213693460e-04f;
+        p = p * s2 + -1.863093246e-03f;
+        p = p * s2 + 1.863326334e-02f;
+        p = p * s2 + -1.314395642e-01f;
+        p = p * s2 + 7.973534865e-01f;
+        const f32x4 e = p * sc;
+        const f32x4 hv = v * 0.5f;
+        return hv * e + hv;
     }
 }
 
@@ -360,7 +361,7 @@ constexpr int k256StripStride = 64 * 2 + 16;                     // 16-row strip
 constexpr int k256BiasOff = 2 * k256Stage + 8 * 16 * k256StripStride;  // two 1 KB bias slots (tile parity)
 constexpr int k256Lds = k256BiasOff + 2 * 1024;                        // 153600 B
 
-template <int EPI>
+template <int EPI, int DEV = 0>   // DEV 1: s_memtime stamps of wave 0 / 4 of workgroup 0 into xres (development only)
 __global__ void __launch_bounds__(512)
 gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     typedef bf16_t T;
@@ -384,6 +385,16 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     if (n_my == 0) return;
 
     const int nk = a.K >> 6, nk1 = a.K1 >> 6;
+    unsigned long long* stamps = nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if constexpr (DEV == 1) {
+            if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && n_stamp < 60)
+                stamps[(wave >> 2) * 64 + n_stamp] = __builtin_readcyclecounter();
+            ++n_stamp;
+        }
+    };
+    if constexpr (DEV == 1) stamps = reinterpret_cast<unsigned long long*>(a.xres);
     const long long sa1 = (long long)a.lda * 2, sa2 = (long long)a.lda2 * 2, sw = (long long)a.K * 2;
 
     // LDS-DMA addressing: wave-uniform 64-bit base (SGPRs) + ONE 32-bit per-lane offset per operand.
@@ -475,37 +486,38 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
             for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], f.b[j], f.a[i]);  // A-operand = W rows
         mma_chunk<T>(accx, wr == 0 ? f.b[0] : f.b[1], f.x);
     };
-    auto compute = [&](int buf) {
-        if (a.ablate & 4) return;
+    // 9 MFMAs of this k-step with the 7 fragment reads of the next one packed EARLY (2 reads behind each of the
+    // first MFMAs): the lgkmcnt(0) in front of the next step is then covered by 5 MFMAs instead of 2.
+    auto interleave = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+    };
+    // `prefetch` (the LDS-DMA of the next k-tile) is issued AFTER this k-tile's first fragment reads, so their
+    // latency overlaps the 9-17 DMA instructions instead of following them.
+    auto compute = [&](int buf, auto&& prefetch) {
+        if (a.ablate & 4) { prefetch(); return; }
         const unsigned st = smem_lds + buf * k256Stage;
         pin_offsets();
         Frags f0, f1;
         load_frags(st, 0, f0);
-        __builtin_amdgcn_sched_barrier(0);   // step 0's own fragments stay ahead of the MFMA region
+        __builtin_amdgcn_sched_barrier(0);   // step 0's own fragments stay ahead of the DMA issue and the MFMA region
+        prefetch();
+        __builtin_amdgcn_sched_barrier(0);
         load_frags(st, 1, f1);
         mma_step(f0);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        interleave();
         load_frags(st, 2, f0);
         mma_step(f1);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        interleave();
         load_frags(st, 3, f1);
         mma_step(f0);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        interleave();
         mma_step(f1);
     };
 
@@ -586,6 +598,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                     }
                 }
             }
+            stamp();
         }
         // tail rows: lane = tail row index (valid below part.e), registers = this wave's 32 columns
         if (part.e > 0) {
@@ -613,6 +626,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     int lin = tile_of(0);
     int tm = lin / n_tiles, tn = lin - tm * n_tiles;
     stage(tm, tn, 0, 0, 0, true);
+    stamp();
     int buf = 0;
     bool stores_in_flight = false;
     for (int i = 0; i < n_my; ++i) {
@@ -635,13 +649,16 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
             if (kt == 0 && stores_in_flight) wait_vmcnt<N_EPI_STORES>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1, false);
-            else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1, false);
-            compute(buf);
+            compute(buf, [&]() {
+                if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1, false);
+                else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1, false);
+            });
             buf ^= 1;
         }
         if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) { stores_in_flight = false; lin = lin_next; tm = tm_next; tn = tn_next; continue; }
+        stamp();
         epilogue(lin, i & 1);
+        stamp();
         stores_in_flight = true;
         lin = lin_next; tm = tm_next; tn = tn_next;
     }
@@ -709,10 +726,11 @@ bool plan256(int M, int N, int K, int K1, Part256& p) {
     return true;
 }
 
-hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipStream_t s) {
+hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipStream_t s, int dev = 0) {
     const int tiles = p.q * (a.N / 256);
     int grid = g_num_cus;
     if (tiles < grid) grid = (tiles + 7) / 8 * 8;   // multiple of 8 (XCD grouping)
+    if (dev == 1) { hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU, 1>), dim3(grid), dim3(512), k256Lds, s, a, p); return hipGetLastError(); }
 #define DD_LAUNCH(E)                                                                                  \
     {                                                                                                 \
         hipLaunchKernelGGL((gemm256_kernel<E>), dim3(grid), dim3(512), k256Lds, s, a, p);             \
@@ -756,6 +774,7 @@ hipError_t init_gemm_kernels() {
         e = hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
     DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE)
 #undef DD_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS_GELU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
     int dev = 0;
     hipDeviceProp_t prop;
     if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -784,6 +803,10 @@ hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, 
         if (a.N <= 64) return launch_cfg<T, 128, 64, 2, 2, 2>(a, epilogue, s);  // decoder_pred: N = P*P*C <= 64
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
     } else {
+        if (variant == 14) {
+            Part256 p;
+            if (plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, EPI_BIAS_GELU, p, s, 1);
+        }
         if (variant == 8) {
             Part256 p;
             if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, epilogue, p, s);
