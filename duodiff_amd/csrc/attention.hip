@@ -16,12 +16,15 @@
 // Works in bf16 (v_mfma_f32_32x32x16_bf16) and in the fp32 parity mode (v_mfma_f32_32x32x2_f32).
 #include "dd_internal.h"
 
+#include <type_traits>
+
 namespace dd {
 namespace {
 
 constexpr int kMaxKeyTiles = 9;          // 9 x 32 = 288 >= 258
 constexpr int kLP = kMaxKeyTiles * 32;   // padded key count held in LDS
 constexpr int kHD = 64;
+constexpr int kPartBytes = 4 * 2 * 66 * 4;   // split last query chunk: [4 waves][2 queries][64 d, max, sum] fp32
 
 template <typename T> struct AttnLayout;
 template <> struct AttnLayout<bf16_t> {
@@ -110,97 +113,91 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     load_q(wave, qnext);   // in flight while the K/V tiles are being staged
     __syncthreads();
 
-    const int nqc = (L + 31) / 32;
-    for (int qc = wave; qc < nqc; qc += 4) {
-        const int q = qc * 32 + r32;
-        f32x4 qcur[NQF];
+    // One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
+    // O^T (two 32(d) x 32(q) tiles), the chunk's running max and the sum of exponentials.
+    auto attend = [&](auto nt_tag, auto&& tile, const f32x4 (&qcur)[NQF], f32x16 (&o)[2], float& mx, float& sum) {
+        constexpr int NT = decltype(nt_tag)::value;
+        // ---- S^T = K . Q^T, tiles of 32 keys x 32 queries
+        f32x16 s[NT];
 #pragma unroll
-        for (int i = 0; i < NQF; ++i) qcur[i] = qnext[i];
-        if (qc + 4 < nqc) load_q(qc + 4, qnext);       // next chunk's Q lands under this chunk's work
-
-        // ---- S^T = K . Q^T, nkt tiles of 32 keys x 32 queries
-        f32x16 s[kMaxKeyTiles];
+        for (int k = 0; k < NT; ++k)
 #pragma unroll
-        for (int t = 0; t < kMaxKeyTiles; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+            for (int e = 0; e < 16; ++e) s[k][e] = 0.f;
 
         if constexpr (sizeof(T) == 2) {
             bf16x8 qf[4];
 #pragma unroll
             for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
 #pragma unroll
-            for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (NKT > 0 ? t < NKT : t < nkt) {
+            for (int k = 0; k < NT; ++k) {
+                const int t = tile(k);
+                if (t >= 0) {
                     const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
                         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
-                        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[t], 0, 0, 0);
+                        s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[k], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the next tile's K reads from being hoisted (and spilled)
                 }
             }
         } else {
             // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
-            f32x4 qf[8];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) qf[g] = qcur[g];
-#pragma unroll
-            for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (NKT > 0 ? t < NKT : t < nkt) {
+            for (int k = 0; k < NT; ++k) {
+                const int t = tile(k);
+                if (t >= 0) {
                     const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + g * 16);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], s[t], 0, 0, 0);
+                            s[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qcur[g][e], s[k], 0, 0, 0);
                     }
                 }
             }
         }
 
-        // ---- softmax over keys (registers x tiles in-lane, then the other lane-half).
-        // softmax(s/8) = exp2((s - max s) * log2(e)/8) / sum: the 1/sqrt(64) scale rides in the exp2
-        // argument; only the last key tile can hold padded keys, so only it is masked.
-        float mx = -INFINITY;
+        // ---- softmax numerators over these keys (registers x tiles in-lane, then the other lane-half).
+        // exp2((s - max s) * log2(e)/8): the 1/sqrt(64) scale rides in the exp2 argument; only the last key tile of
+        // the sequence can hold padded keys, so only it is masked.
+        mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < kMaxKeyTiles; ++t) {
-            if (NKT > 0 ? t < NKT : t < nkt) {
-                if (NKT > 0 ? t == NKT - 1 : t == nkt - 1) {
+        for (int k = 0; k < NT; ++k) {
+            const int t = tile(k);
+            if (t >= 0) {
+                if (t == nkt - 1) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                        if (key >= L) s[t][e] = -INFINITY;
+                        if (key >= L) s[k][e] = -INFINITY;
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[k][e]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
         const float mxs = mx * kScaleLog2e;
-        float sum = 0.f;
+        sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < kMaxKeyTiles; ++t) {
-            if (NKT > 0 ? t < NKT : t < nkt) {
+        for (int k = 0; k < NT; ++k) {
+            if (tile(k) >= 0) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float p;
-                    if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[t][e], kScaleLog2e, -mxs));
-                    else p = expf((s[t][e] - mx) * 0.125f);
-                    s[t][e] = p;
+                    if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[k][e], kScaleLog2e, -mxs));
+                    else p = expf((s[k][e] - mx) * 0.125f);
+                    s[k][e] = p;
                     sum += p;
                 }
             }
         }
         sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
 
         // ---- O^T = V^T . P^T : two 32(d) x 32(q) tiles
-        f32x16 o[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -208,15 +205,16 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (NKT > 0 ? t < NKT : t < nkt) {
+            for (int k = 0; k < NT; ++k) {
+                const int t = tile(k);
+                if (t >= 0) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
                         // t*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
                         bf16x8 pf;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[t][8 * st + j]);
+                        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[k][8 * st + j]);
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
                             const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 16 * st + 4 * half) * 2;
@@ -234,8 +232,9 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < kMaxKeyTiles; ++t) {
-                if (NKT > 0 ? t < NKT : t < nkt) {
+            for (int k = 0; k < NT; ++k) {
+                const int t = tile(k);
+                if (t >= 0) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         // registers 4g..4g+3 are keys t*32 + 8g + 4*half + (0..3): contiguous in V^T
@@ -245,12 +244,32 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                             const f32x4 vf = *reinterpret_cast<const f32x4*>(vr);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[t][4 * g + e], o[dt], 0, 0, 0);
+                                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[k][4 * g + e], o[dt], 0, 0, 0);
                         }
                     }
                 }
             }
         }
+    };
+
+    // L = 32*8 + 1 or 2 (every shipped config): the 9th query chunk holds only the extra time / label tokens.  Given to
+    // one wave it would cost a whole chunk (3 chunks on one wave against 2 on the others = +25 % on the workgroup); instead
+    // all four waves take it together, each against its own key tiles, and the partial results are merged through LDS.
+    constexpr bool SPLIT_LAST = NKT == 9;
+    const int nqc = (L + 31) / 32;
+    const int n_regular = SPLIT_LAST ? 8 : nqc;
+    for (int qc = wave; qc < n_regular; qc += 4) {
+        const int q = qc * 32 + r32;
+        f32x4 qcur[NQF];
+#pragma unroll
+        for (int i = 0; i < NQF; ++i) qcur[i] = qnext[i];
+        if (qc + 4 < n_regular) load_q(qc + 4, qnext);       // next chunk's Q lands under this chunk's work
+        else if (SPLIT_LAST) load_q(8, qnext);
+
+        f32x16 o[2];
+        float mx, sum;
+        attend(std::integral_constant<int, kMaxKeyTiles>{}, [&](int k) { return k < nkt ? k : -1; }, qcur, o, mx, sum);
+        const float inv = 1.0f / sum;
 
         // ---- store: lane = query, registers = d ; 4 consecutive d per register quad
         if (q < L) {
@@ -271,6 +290,42 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                 }
         }
     }
+
+    if constexpr (SPLIT_LAST) {
+        // wave w: key tiles w, w+4 and (wave 3) the 9th tile, which holds the keys of the extra tokens themselves
+        float* part = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + kHD * Lay::kRowV);   // [4 waves][2 queries][64 d + max + sum]
+        const int rem = L - 256;                                                               // 1 or 2 valid queries
+        f32x16 o[2];
+        float mx, sum;
+        attend(std::integral_constant<int, 3>{}, [&](int k) { return k < 2 ? wave + 4 * k : (wave == 3 ? 8 : -1); }, qnext, o, mx, sum);
+        if (r32 < rem) {
+            float* pw = part + (wave * 2 + r32) * 66;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(pw + dt * 32 + 8 * g + 4 * half) =
+                        f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+            if (half == 0) { pw[64] = mx; pw[65] = sum; }
+        }
+        __syncthreads();
+        if (tid < rem * 64) {
+            const int qi = tid >> 6, d = tid & 63;
+            float m[4], M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { m[w] = part[(w * 2 + qi) * 66 + 64]; M = fmaxf(M, m[w]); }
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float f;
+                if constexpr (sizeof(T) == 2) f = __builtin_amdgcn_exp2f((m[w] - M) * (0.125f * 1.4426950408889634f));
+                else f = expf((m[w] - M) * 0.125f);
+                num = fmaf(f, part[(w * 2 + qi) * 66 + d], num);
+                den = fmaf(f, part[(w * 2 + qi) * 66 + 65], den);
+            }
+            out[((long long)b * L + 256 + qi) * D + hh * kHD + d] = Elem<T>::from_f32(num / den);
+        }
+    }
 }
 
 }  // namespace
@@ -279,15 +334,15 @@ template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s) {
     if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
     using Lay = AttnLayout<T>;
-    const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)kHD * Lay::kRowV;
+    const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)kHD * Lay::kRowV + kPartBytes;
     if ((L + 31) / 32 == 9) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     return hipGetLastError();
 }
 
 hipError_t init_attention_kernels() {
-    const int lb = kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV;
-    const int lf = kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV;
+    const int lb = kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV + kPartBytes;
+    const int lf = kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV + kPartBytes;
     hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<float, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lf);
