@@ -1,9 +1,10 @@
 """ctypes binding of libduodiff.so (include/duodiff.h).  No CPU fallback: a missing
 library is an ImportError-class failure raised at first use, loudly."""
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libduodiff.so"
+LIB_PATH = Path(os.environ.get("DUODIFF_LIB") or Path(__file__).resolve().parent / "libduodiff.so")
 
 DD_OK = 0
 DD_ERR_INVALID, DD_ERR_NOT_FOUND, DD_ERR_STATE, DD_ERR_HIP, DD_ERR_NOMEM, DD_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6

@@ -58,28 +58,55 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte chunk
     constexpr int CPR = kHD / EPC;                     // chunks per row (8 bf16 / 16 fp32)
 
+    // Q fragments of a 32-query chunk, straight from HBM/L2 (rows >= L are clamped and dropped later)
+    constexpr int NQF = sizeof(T) == 2 ? 4 : 8;
+    auto load_q = [&](int qc, f32x4 (&qf)[NQF]) {
+        const int q = qc * 32 + r32;
+        const T* qrow = qbase + (long long)(q < L ? q : L - 1) * ld;
+#pragma unroll
+        for (int i = 0; i < NQF; ++i)
+            qf[i] = sizeof(T) == 2 ? *reinterpret_cast<const f32x4*>(qrow + 16 * i + 8 * half)
+                                   : *reinterpret_cast<const f32x4*>(qrow + 32 * half + 4 * i);
+    };
+    f32x4 qnext[NQF];
+    load_q(wave, qnext);   // first: in flight while the K/V tiles are being staged
+
     // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
     if constexpr (sizeof(T) == 2) {
-        // two keys per item, so V^T goes in as dwords {V[2k][d], V[2k+1][d]} instead of 2-byte writes
+        // two keys per item, so V^T goes in as dwords {V[2k][d], V[2k+1][d]} instead of 2-byte writes.
+        // All loads of the (at most 5) items of a thread are issued BEFORE the first LDS write: written as a plain loop the
+        // compiler keeps load -> wait -> write per iteration, i.e. five serial HBM round trips per workgroup.
         const int items = nkt * 16 * CPR;
-        for (int idx = tid; idx < items; idx += 256) {
-            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
-            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-            if (key < L) {
-                k0 = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
-                v0 = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
-            }
-            if (key + 1 < L) {
-                k1 = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
-                v1 = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
-            }
-            *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0;
-            *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1;
-            const bf16x8 a = __builtin_bit_cast(bf16x8, v0), b = __builtin_bit_cast(bf16x8, v1);
+        constexpr int ITER = (kMaxKeyTiles * 16 * CPR + 255) / 256;
+        f32x4 k0[ITER], k1[ITER], v0[ITER], v1[ITER];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned pair = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
-                *reinterpret_cast<unsigned*>(Vt + (ch * 8 + e) * Lay::kRowV + key * 2) = pair;
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
+            k0[it] = k1[it] = v0[it] = v1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < items && key < L) {
+                k0[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
+                v0[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
+            }
+            if (idx < items && key + 1 < L) {
+                k1[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
+                v1[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
+            if (idx < items) {
+                *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0[it];
+                *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1[it];
+                const bf16x8 a = __builtin_bit_cast(bf16x8, v0[it]), b = __builtin_bit_cast(bf16x8, v1[it]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned pair = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
+                    *reinterpret_cast<unsigned*>(Vt + (ch * 8 + e) * Lay::kRowV + key * 2) = pair;
+                }
             }
         }
     } else {
@@ -99,18 +126,6 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         }
     }
 
-    // Q fragments of a 32-query chunk, straight from HBM/L2 (rows >= L are clamped and dropped later)
-    constexpr int NQF = sizeof(T) == 2 ? 4 : 8;
-    auto load_q = [&](int qc, f32x4 (&qf)[NQF]) {
-        const int q = qc * 32 + r32;
-        const T* qrow = qbase + (long long)(q < L ? q : L - 1) * ld;
-#pragma unroll
-        for (int i = 0; i < NQF; ++i)
-            qf[i] = sizeof(T) == 2 ? *reinterpret_cast<const f32x4*>(qrow + 16 * i + 8 * half)
-                                   : *reinterpret_cast<const f32x4*>(qrow + 32 * half + 4 * i);
-    };
-    f32x4 qnext[NQF];
-    load_q(wave, qnext);   // in flight while the K/V tiles are being staged
     __syncthreads();
 
     // One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
@@ -128,18 +143,27 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             bf16x8 qf[4];
 #pragma unroll
             for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
+            // K fragments double-buffered: tile k+1's four ds_read_b128 are issued before tile k's MFMAs, so the LDS latency
+            // hides under them (the plain read -> wait -> MFMA chain spent most of a chunk in s_waitcnt lgkmcnt)
+            auto load_k = [&](int t, bf16x8 (&kf)[4]) {
+                const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
+            };
+            bf16x8 kfa[4], kfb[4];
+            if (tile(0) >= 0) load_k(tile(0), kfa);
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int t = tile(k);
+                const int tn = k + 1 < NT ? tile(k + 1) : -1;
+                if (tn >= 0) { if (k & 1) load_k(tn, kfa); else load_k(tn, kfb); }
+                __builtin_amdgcn_sched_barrier(0);  // the look-ahead reads go out BEFORE this tile's MFMAs
                 if (t >= 0) {
-                    const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
 #pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
-                        s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[k], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's K reads from being hoisted (and spilled)
+                    for (int st = 0; st < 4; ++st)
+                        s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[st] : kfa[st], qf[st], s[k], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // one tile of look-ahead, no further hoisting (it would spill)
             }
         } else {
             // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
@@ -204,10 +228,29 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
 
         if constexpr (sizeof(T) == 2) {
+            // V^T fragments double-buffered like the K fragments: [st][dt], keys t*32 + 16*st + 4*half + {0..3, 8..11}
+            typedef __attribute__((ext_vector_type(4))) short s4;
+            struct VF { s4 lo[2][2], hi[2][2]; };
+            auto load_v = [&](int t, VF& f) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 16 * st + 4 * half) * 2;
+                        f.lo[st][dt] = *reinterpret_cast<const s4*>(vr);        // keys +0..3
+                        f.hi[st][dt] = *reinterpret_cast<const s4*>(vr + 16);   // keys +8..11
+                    }
+            };
+            VF va, vb;
+            if (tile(0) >= 0) load_v(tile(0), va);
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int t = tile(k);
+                const int tn = k + 1 < NT ? tile(k + 1) : -1;
+                if (tn >= 0) { if (k & 1) load_v(tn, va); else load_v(tn, vb); }
+                __builtin_amdgcn_sched_barrier(0);
                 if (t >= 0) {
+                    const VF& f = (k & 1) ? vb : va;
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
@@ -217,18 +260,14 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                         for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[k][8 * st + j]);
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
-                            const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 16 * st + 4 * half) * 2;
-                            typedef __attribute__((ext_vector_type(4))) short s4;
-                            const s4 lo = *reinterpret_cast<const s4*>(vr);        // keys +0..3
-                            const s4 hi = *reinterpret_cast<const s4*>(vr + 16);   // keys +8..11
                             bf16x8 vf;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                            for (int j = 0; j < 4; ++j) { vf[j] = f.lo[st][dt][j]; vf[4 + j] = f.hi[st][dt][j]; }
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
