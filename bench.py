@@ -187,7 +187,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(REPO / "profiles" / "r01_pmc_traffic.json"))
-            k = next(v for n, v in pmc.items() if "gemm256_kernel<1>" in n)
+            k = next(v for n, v in pmc.items() if "gemm256_kernel<1>" in n or "gemm256_kernel<1, 0>" in n)
             traffic = (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6
         except Exception:
             pass
@@ -208,7 +208,10 @@ def main():
                          "algorithmic_bytes": (B * mp_f.seq_len * mp_f.embed_dim + 4 * mp_f.embed_dim * mp_f.embed_dim + B * mp_f.seq_len * 4 * mp_f.embed_dim) * 2,
                          "kernel": "gemm256_kernel<EPI_BIAS_GELU> (fc1: bias + exact-erf GELU fused) M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
                          "ms_per_launch": ms, "launches_timed": n_launch, "flops_per_launch": fl,
-                         "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS},
+                         "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "sustained_mfma_tflops_random_operands": 1910.0,
+                         "sustained_note": "register-only v_mfma_f32_32x32x16_bf16 loop, random operands, measured on MI355X "
+                                           "(tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
         }
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline ...")
