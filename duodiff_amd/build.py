@@ -53,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [cc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [cc, *FLAGS, *os.environ.get("DD_EXTRA_HIPCC_FLAGS", "").split(), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -82,6 +82,84 @@ void run_random_burst(int iters, int launches) {
     hipFree(d);
 }
 
+// co-execution probe: NV independent packed-fp32 FMAs issued after every MFMA (MODE 0: MFMA only, 1: both, 2: VALU only)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE, int NV>
+__global__ void __launch_bounds__(256) coexec(float* out, int iters) {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)((threadIdx.x * 7 + e) & 15); b[e] = (__bf16)(float)((threadIdx.x + e * 3) & 7); }
+    f32x2 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = f32x2{(float)threadIdx.x + i, 1.0f};
+    const f32x2 m = {0.999f, 1.001f}, c = {0.5f, -0.25f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE != 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            if (MODE != 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[(i + k) & 7] = __builtin_elementwise_fma(v[(i + k) & 7], m, c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + v[i][0] + v[i][1];
+    if (s == 12345.f) out[0] = s;
+}
+// same probe with plain (unpacked) v_fma_f32
+template <int MODE, int NV>
+__global__ void __launch_bounds__(256) coexec1(float* out, int iters) {
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)((threadIdx.x * 7 + e) & 15); b[e] = (__bf16)(float)((threadIdx.x + e * 3) & 7); }
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = (float)threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE != 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            if (MODE != 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[(i + k) & 7] = __builtin_fmaf(v[(i + k) & 7], 0.999f, 0.5f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + v[i];
+    if (s == 12345.f) out[0] = s;
+}
+template <int MODE, int NV>
+void run_coexec1(int iters, const char* name) {
+    float* d; hipMalloc(&d, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((coexec1<MODE, NV>), dim3(512), dim3(256), 0, 0, d, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((coexec1<MODE, NV>), dim3(512), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("coexec1 %-27s NV=%d: %.3f ms\n", name, NV, ms);
+    hipFree(d);
+}
+
+template <int MODE, int NV>
+void run_coexec(int iters, const char* name) {
+    float* d; hipMalloc(&d, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((coexec<MODE, NV>), dim3(512), dim3(256), 0, 0, d, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((coexec<MODE, NV>), dim3(512), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("coexec %-28s NV=%d: %.3f ms\n", name, NV, ms);
+    hipFree(d);
+}
+
 template <int NACC>
 void run(int waves_per_simd, int iters, const char* name) {
     float* d; hipMalloc(&d, 4);
@@ -109,6 +187,15 @@ int main(int argc, char** argv) {
     run<8>(2, iters * 10, "8 acc long");
     run_random(iters / 2);
     run_random(iters * 5);
+    run_coexec<0, 4>(iters, "MFMA only (2 waves/SIMD)");
+    run_coexec<1, 4>(iters, "MFMA + 4 pk_fma each");
+    run_coexec<2, 4>(iters, "4 pk_fma only");
+    run_coexec<1, 6>(iters, "MFMA + 6 pk_fma each");
+    run_coexec<2, 6>(iters, "6 pk_fma only");
+    run_coexec1<1, 4>(iters, "MFMA + 4 v_fma each");
+    run_coexec1<2, 4>(iters, "4 v_fma only");
+    run_coexec1<1, 7>(iters, "MFMA + 7 v_fma each");
+    run_coexec1<2, 7>(iters, "7 v_fma only");
     run_random_burst(128, 20);    // ~35 us of MFMA per launch at 1.9 PF
     run_random_burst(128, 200);
     run_random_burst(32, 200);    // = one 256x256x512 tile stream of 4 tiles per CU
