@@ -365,7 +365,7 @@ template <int EPI, int DEV = 0>   // DEV 1: s_memtime stamps of wave 0 / 4 of wo
 __global__ void __launch_bounds__(512)
 gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     typedef bf16_t T;
-    constexpr int TM = 4, TN = 2, NW = 8;
+    constexpr int TM = 4, TN = 2;
     constexpr int A_BYTES = k256ARows * 128;
     constexpr int N_EPI_STORES = (EPI == EPI_STORE || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_STORE) ? TM * 4 : TM * TN * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,7 +395,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         }
     };
     if constexpr (DEV == 1) stamps = reinterpret_cast<unsigned long long*>(a.xres);
-    const long long sa1 = (long long)a.lda * 2, sa2 = (long long)a.lda2 * 2, sw = (long long)a.K * 2;
+    const long long sa1 = (long long)a.lda * 2, sw = (long long)a.K * 2;   // lda2 == lda (checked on the host)
 
     // LDS-DMA addressing: wave-uniform 64-bit base (SGPRs) + ONE 32-bit per-lane offset per operand.
     // Lane l of wave-instruction `inst` writes LDS row r = inst*8 + (l>>3), 16-byte slot l&7, and
