@@ -62,6 +62,11 @@ class Context:
         msg = msg.decode() if msg else f"status {rc}"
         raise _ERR_CLASS.get(rc, RuntimeError)(msg)
 
+    def side_stream(self, device):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def sync(self, stream=None):
         self.check(self.lib.dd_sync(self.handle, _stream_ptr(stream)))
 
@@ -230,5 +235,15 @@ def sample_loop(ctx: Context, first: Model, late, x, *, t_switch=0, t_start=999,
     args.y_dev = y.data_ptr() if y is not None else None
     args.x_dev = x.data_ptr()
     args.B = x.shape[0]
-    ctx.check(ctx.lib.dd_sample(ctx.handle, C.byref(args), _stream_ptr(stream)))
+    cur = stream if stream is not None else torch.cuda.current_stream(x.device)
+    if use_graph and cur.cuda_stream == 0:
+        # hipGraph capture is not permitted on the legacy default stream: run the loop on a private side stream, ordered
+        # after the caller's work and before whatever the caller enqueues next
+        side = ctx.side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ctx.check(ctx.lib.dd_sample(ctx.handle, C.byref(args), _stream_ptr(side)))
+        cur.wait_stream(side)
+    else:
+        ctx.check(ctx.lib.dd_sample(ctx.handle, C.byref(args), _stream_ptr(cur)))
     return x

@@ -328,3 +328,16 @@ def test_conditional_model_full_size_labels():
     y2 = y.clone(); y2[2] = 501
     eps2 = m(x, t, y2).cpu().numpy()
     assert np.array_equal(np.delete(eps, 2, 0), np.delete(eps2, 2, 0)) and not np.array_equal(eps[2], eps2[2])
+
+
+def test_get_samples_device_noise_on_default_stream():
+    """noise="device" replays hipGraphs; called from the default stream (as the CLI does) the loop moves to a side stream
+    instead of failing in hipStreamBeginCapture.  Same seeds -> identical images; intermediate saves split the loop."""
+    from duodiff_amd import sampler
+    m_s, _ = _uvit(dict(TINY, depth=1), 300, "fp32")
+    m_f, _ = _uvit(dict(TINY, depth=3), 301, "fp32")
+    kw = dict(late_model=m_f, t_switch=300, noise="device", num_steps=40)
+    a, _ = sampler.get_samples(m_s, 3, sampler.predict_noise_postprocessing, 7, 3, 8, 8, **kw)
+    b, inter = sampler.get_samples(m_s, 3, sampler.predict_noise_postprocessing, 7, 3, 8, 8, timesteps_save=[20], **kw)
+    assert a.shape == (3, 8, 8, 3) and np.isfinite(a).all()
+    assert np.array_equal(a, b) and len(inter) == 1 and inter[0].shape == (3, 8, 8, 3)
