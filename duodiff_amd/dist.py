@@ -100,9 +100,13 @@ def main(argv=None):
     if args.checkpoint_path_late:
         late, _ = sampler.build_model(sampler.load_config(args.config_path_late), args.checkpoint_path_late,
                                       args.precision, args.batch_size)
-    post = sampler.predict_noise_postprocessing if args.parametrization == "predict_noise" else None
-    if post is None:
-        raise NotImplementedError("only predict_noise is accelerated")
+    post = {"predict_noise": sampler.predict_noise_postprocessing, "predict_original": sampler.predict_original_postprocessing,
+            "predict_previous": sampler.predict_previous_postprocessing}[args.parametrization]
+    autoencoder = None
+    if "autoencoder" in config:
+        from .autoencoder import get_autoencoder
+        path = args.autoencoder_checkpoint_path or config["autoencoder"]["autoencoder_checkpoint_path"]
+        autoencoder = get_autoencoder(path, precision=args.precision).to(model.device)
 
     def one_rank(seed):
         y = None
@@ -110,7 +114,8 @@ def main(argv=None):
             sampler.seed_everything(seed)
             y = torch.randint(1, 1001, (args.batch_size,))
         s, _ = sampler.get_samples(model, args.batch_size, post, seed, mp.in_chans, mp.img_size, mp.img_size,
-                                   timesteps_save=[], y=y, late_model=late, t_switch=args.t_switch,
+                                   use_ddim=args.use_ddim, ddim_steps=args.ddim_steps, ddim_eta=args.ddim_eta,
+                                   timesteps_save=[], y=y, autoencoder=autoencoder, late_model=late, t_switch=args.t_switch,
                                    noise=args.noise, use_graph=not args.no_graph, return_device_tensor=True)
         return s
 

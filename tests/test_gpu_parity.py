@@ -341,3 +341,19 @@ def test_get_samples_device_noise_on_default_stream():
     b, inter = sampler.get_samples(m_s, 3, sampler.predict_noise_postprocessing, 7, 3, 8, 8, timesteps_save=[20], **kw)
     assert a.shape == (3, 8, 8, 3) and np.isfinite(a).all()
     assert np.array_equal(a, b) and len(inter) == 1 and inter[0].shape == (3, 8, 8, 3)
+
+
+def test_sharded_cli_single_rank(tmp_path):
+    """python -m duodiff_amd.dist with WORLD_SIZE unset = one rank: same flags as the sampler, rank 0 writes the output."""
+    import subprocess, sys, yaml
+    cfg = dict(TINY, depth=1, img_size=16)
+    (tmp_path / "m.yaml").write_text(yaml.safe_dump({"model_params": dict(cfg)}))
+    torch.save(dict(synthetic_state_dict(ModelParams.from_dict(cfg), 5)), tmp_path / "m.pth")
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "duodiff_amd.dist", "--seed", "3", "--checkpoint_path", str(tmp_path / "m.pth"), "--config_path",
+           str(tmp_path / "m.yaml"), "--batch_size", "4", "--parametrization", "predict_noise", "--output_folder", str(out), "--no_png",
+           "--precision", "fp32", "--noise", "device", "--use_ddim", "--ddim_steps", "5"]
+    r = subprocess.run(cmd, cwd=str(REPO), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out / "samples.npy")
+    assert got.shape == (4, 16, 16, 3) and np.isfinite(got).all()
