@@ -357,3 +357,20 @@ def test_sharded_cli_single_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out / "samples.npy")
     assert got.shape == (4, 16, 16, 3) and np.isfinite(got).all()
+
+
+def test_workspace_grows_with_batch():
+    """No max_batch given: the engine model is rebuilt when a later call brings a larger batch; results do not depend on it."""
+    cfg = dict(TINY)
+    m, _ = _uvit(cfg, 77, "fp32")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(9, 3, 8, 8, generator=g)
+    t = torch.full((9,), 123.0)
+    e2 = m(x[:2].contiguous(), t[:2]).cpu()
+    e9 = m(x, t).cpu()
+    e2b = m(x[:2].contiguous(), t[:2]).cpu()
+    assert torch.equal(e2, e9[:2]) and torch.equal(e2, e2b)
+    # graph replay after growth: a sampling loop at the larger batch on the default stream
+    from duodiff_amd import sampler
+    s, _ = sampler.get_samples(m, 9, sampler.predict_noise_postprocessing, 1, 3, 8, 8, noise="device", num_steps=10)
+    assert s.shape == (9, 8, 8, 3) and np.isfinite(s).all()
