@@ -185,10 +185,13 @@ def main():
         # HBM bytes of that kernel per launch from the committed two-pass PMC profile (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE; tools/pmc_summary.py) -- rocprofv3 cannot run inside this process
         traffic = None
+        mfma_busy = None
         try:
             pmc = json.load(open(REPO / "profiles" / "r01_pmc_traffic.json"))
             k = next(v for n, v in pmc.items() if "gemm256_kernel<1>" in n or "gemm256_kernel<1, 0>" in n)
             traffic = (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6
+            sq = json.load(open(REPO / "profiles" / "r01_pmc_sq.json"))
+            mfma_busy = next(v["mfma_busy_frac"] for n, v in sq.items() if "gemm256_kernel<1" in n)
         except Exception:
             pass
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
@@ -209,6 +212,8 @@ def main():
                          "kernel": "gemm256_kernel<EPI_BIAS_GELU> (fc1: bias + exact-erf GELU fused) M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
                          "ms_per_launch": ms, "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": 8000.0,
+                         "mfma_busy_frac_pmc": mfma_busy,
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "register-only v_mfma_f32_32x32x16_bf16 loop, random operands, measured on MI355X "
                                            "(tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
