@@ -180,6 +180,10 @@ void run(int waves_per_simd, int iters, const char* name) {
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
+    run<1>(1, iters * 4, "1 acc (dependent chain)");
+    run<2>(1, iters * 2, "2 acc");
+    run<1>(2, iters * 4, "1 acc (dependent chain)");
+    run<2>(2, iters * 2, "2 acc");
     run<4>(1, iters, "4 acc");
     run<8>(1, iters, "8 acc");
     run<8>(2, iters, "8 acc");
