@@ -324,9 +324,8 @@ gemm_kernel(const GemmArgs<T> a) {
 // ride along as one extra 32-row MFMA tile per wave (+12.5 % MFMA issue, no extra weight traffic).
 //
 // 8 waves = 2 (M) x 4 (N); wave tile 128 x 64 (4 x 2 MFMA 32x32x16 tiles) + 1 tail tile.
-// LDS: 2 stages x (264 A rows + 256 W rows) x 128 B = 130 KB, + 8 wave-private 16-row strips for
-// the bf16 output transpose (inline-asm DS ops: hipcc would otherwise wait vmcnt(0) before every
-// strip write and may sink the strip reads into the exec-masked write branch).
+// LDS: 2 stages x (264 A rows + 256 W rows) x 128 B = 130 KB + two 1 KB bias slots.  The bf16 output leaves
+// straight from registers (v_permlane32_swap pairs the two lane halves into 16-byte row segments).
 // ------------------------------------------------------------------------------------------
 struct Part256 {  // host-computed row partition
     int q;          // main M-tiles (256 rows each)
@@ -337,9 +336,6 @@ struct Part256 {  // host-computed row partition
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
-__device__ __forceinline__ void asm_ds_write_b64(unsigned addr, uint2 v) {
-    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
 // four 16-byte LDS reads at addr + {0, 32, 64, 96} bytes, one wait
 __device__ __forceinline__ void asm_ds_read_4x_b128_wait(unsigned addr, f32x4 (&r)[4]) {
     asm volatile(
@@ -349,17 +345,10 @@ __device__ __forceinline__ void asm_ds_read_4x_b128_wait(unsigned addr, f32x4 (&
         : "v"(addr)
         : "memory");
 }
-__device__ __forceinline__ f32x4 asm_ds_read_b128_wait(unsigned addr) {
-    f32x4 r;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
-    return r;
-}
-
 constexpr int k256ARows = 264;                                   // 256 main + 8 tail rows
 constexpr int k256Stage = (k256ARows + 256) * 128;               // 66560 B
-constexpr int k256StripStride = 64 * 2 + 16;                     // 16-row strip of 64 bf16 columns
-constexpr int k256BiasOff = 2 * k256Stage + 8 * 16 * k256StripStride;  // two 1 KB bias slots (tile parity)
-constexpr int k256Lds = k256BiasOff + 2 * 1024;                        // 153600 B
+constexpr int k256BiasOff = 2 * k256Stage;                       // two 1 KB bias slots (tile parity)
+constexpr int k256Lds = k256BiasOff + 2 * 1024;                  // 135168 B
 
 template <int EPI, int DEV = 0>   // DEV 1: s_memtime stamps of wave 0 / 4 of workgroup 0 into xres (development only)
 __global__ void __launch_bounds__(512)
@@ -374,7 +363,6 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int h = lane >> 5, r32 = lane & 31;
-    const unsigned strip = lds_addr(smem + 2 * k256Stage + wave * (16 * k256StripStride));
 
     const int n_tiles = a.N >> 8;
     const int total = part.q * n_tiles;
@@ -526,7 +514,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     //    a load's wait would also wait for every older store): the bias comes from LDS, and the
     //    residual x is software-pipelined -- the loads of unit u+1 are issued BEFORE the stores of
     //    unit u, so waiting for them only retires stores that are two units old;
-    //  * the bf16 copy leaves through the wave-private strip as whole 16-byte row segments.
+    //  * the bf16 copy leaves as 16-byte row segments built in registers (v_permlane32_swap), no LDS round trip.
     auto pack4 = [](const f32x4& q) -> uint2 {   // two v_cvt_pk_bf16_f32, no mask/shift glue
         typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
         const bf16v4 b = __builtin_convertvector(q, bf16v4);
@@ -579,24 +567,21 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                 }
             }
             if (use_out) {
+                // bf16 copy of this 32-row slab straight from registers: quads g and g+1 of a column block hold, on lane (r, h=0),
+                // columns 8g..8g+3 and 8g+8..8g+11 of row r and on lane (r, h=1) columns 8g+4..8g+7 and 8g+12..8g+15;
+                // v_permlane32_swap (upper half of the first register <-> lower half of the second) makes that 16 contiguous
+                // bytes per lane -- columns 8g..8g+7 on h=0, 8g+8..8g+15 on h=1 -- so the slab leaves as 16-byte stores without
+                // the LDS strip round trip (and its lgkmcnt(0) waits) the first version of this epilogue needed.
+                const long long orow = (long long)tm * 256 + wr * 128 + i * 32 + r32;
 #pragma unroll
-                for (int half16 = 0; half16 < 2; ++half16) {
-                    if ((r32 >> 4) == half16) {
-                        const unsigned sp = strip + (r32 & 15) * k256StripStride + 8 * h;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) asm_ds_write_b64(sp + (j * 32 + 8 * g) * 2, v[j][g]);
+                    for (int gp = 0; gp < 4; gp += 2) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(v[j][gp].x, v[j][gp + 1].x, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(v[j][gp].y, v[j][gp + 1].y, false, false);
+                        const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        if (!(a.ablate & 16)) *reinterpret_cast<uint4*>(a.out + orow * a.ldo + col0 + j * 32 + 8 * gp + 8 * h) = o;
                     }
-                    // 16 rows x 128 B back out as 16-byte row segments: 8 lanes per row, 8 rows per instruction
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int sr = it * 8 + (lane >> 3), sc = lane & 7;
-                        const f32x4 q = asm_ds_read_b128_wait(strip + sr * k256StripStride + sc * 16);
-                        const long long orow = (long long)tm * 256 + wr * 128 + i * 32 + half16 * 16 + sr;
-                        if (!(a.ablate & 16)) *reinterpret_cast<f32x4*>(a.out + orow * a.ldo + col0 + sc * 8) = q;
-                    }
-                }
             }
             stamp();
         }
