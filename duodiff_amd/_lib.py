@@ -36,6 +36,7 @@ SIGNATURES = {
     "dd_last_error": (C.c_char_p, [C.c_void_p]),
     "dd_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dd_schedule_table": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "dd_schedule_build": (C.c_int, [C.c_float, C.c_float, C.c_int] + [C.POINTER(C.c_float)] * 5),
     "dd_model_create": (C.c_int, [C.c_void_p, C.POINTER(dd_config), C.POINTER(C.c_void_p)]),
     "dd_model_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "dd_model_finalize": (C.c_int, [C.c_void_p, C.c_int]),
@@ -48,10 +49,13 @@ SIGNATURES = {
     "dd_early_exit_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dd_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dd_ddpm_step_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "dd_affine_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "dd_sample_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dd_to_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dd_sample": (C.c_int, [C.c_void_p, C.POINTER(dd_sample_args), C.c_void_p]),
     "dd_bench_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "dd_vae_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -111,30 +111,42 @@ int fail_hip(dd_ctx* c, hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail_hip((c), _e, #expr);   \
     } while (0)
 
-// ---- schedule: bit-for-bit the fp32 tables of sampler.py:40-44 (see oracle/schedule_oracle.py)
+// ---- schedule: bit-for-bit the fp32 tables of sampler.py:40-44 / ddpm_core.py:64-70 (see oracle/schedule_oracle.py)
+// betas = torch.linspace(beta_init, beta_final, n): ATen rounds once per element, forward from start in the first half,
+// backward from end in the second; alphas_bar = torch.cumprod: the CPU scan accumulates in double, rounds each output.
+void base_tables(float beta_init, float beta_final, int n, float* betas, float* alphas, float* abar, float* abar_prev) {
+    const float start = beta_init, end = beta_final;
+    const float stepf = n > 1 ? (end - start) / (float)(n - 1) : 0.0f;
+    const double step = (double)stepf;
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) {
+        betas[i] = i < half ? (float)((double)start + step * i) : (float)((double)end - step * (n - 1 - i));
+        alphas[i] = 1.0f - betas[i];
+    }
+    double run = 1.0;
+    for (int i = 0; i < n; ++i) {
+        run *= (double)alphas[i];
+        abar[i] = (float)run;
+    }
+    for (int i = 0; i < n; ++i) abar_prev[i] = i ? abar[i - 1] : 1.0f;
+}
+float bt_sampler_order(float beta, float abar_prev, float abar) {   // sampler.py:44: betas * (1 - abar_prev) / (1 - abar)
+    volatile float num = beta * (1.0f - abar_prev);
+    return num / (1.0f - abar);
+}
+float bt_scheduler_order(float beta, float abar_prev, float abar) {   // ddpm_core.py:68-70: (1 - abar_prev) / (1 - abar) * betas
+    volatile float ratio = (1.0f - abar_prev) / (1.0f - abar);
+    return ratio * beta;
+}
+
 struct Schedule {
     float betas[1000], alphas[1000], abar[1000], abar_prev[1000], bt_sampler[1000], bt_sched[1000];
     float c1[1000], c2[1000], sigma[1000], sigma_beta[1000];
     Schedule() {
-        const float start = 1e-4f, end = 0.02f;
-        const float stepf = (end - start) / 999.0f;
-        const double step = (double)stepf;
+        base_tables(1e-4f, 0.02f, 1000, betas, alphas, abar, abar_prev);
         for (int i = 0; i < 1000; ++i) {
-            // torch.linspace: one rounding per element, forward from start / backward from end
-            betas[i] = i < 500 ? (float)((double)start + step * i) : (float)((double)end - step * (999 - i));
-            alphas[i] = 1.0f - betas[i];
-        }
-        double run = 1.0;  // torch.cumprod (CPU) accumulates in double, rounds each output
-        for (int i = 0; i < 1000; ++i) {
-            run *= (double)alphas[i];
-            abar[i] = (float)run;
-        }
-        for (int i = 0; i < 1000; ++i) abar_prev[i] = i ? abar[i - 1] : 1.0f;
-        for (int i = 0; i < 1000; ++i) {
-            volatile float num = betas[i] * (1.0f - abar_prev[i]);
-            bt_sampler[i] = num / (1.0f - abar[i]);
-            volatile float ratio = (1.0f - abar_prev[i]) / (1.0f - abar[i]);
-            bt_sched[i] = ratio * betas[i];
+            bt_sampler[i] = bt_sampler_order(betas[i], abar_prev[i], abar[i]);
+            bt_sched[i] = bt_scheduler_order(betas[i], abar_prev[i], abar[i]);
             c1[i] = sqrtf(1.0f / alphas[i]);
             c2[i] = (1.0f - alphas[i]) / sqrtf(1.0f - abar[i]);
             sigma[i] = sqrtf(bt_sampler[i]);
@@ -323,7 +335,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s));
             const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
             FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
-                         c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
+                         c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
             DD_HIP(c, launch_final(fa, s));
             const int pi = m->ee_type == DD_EE_MLP_PER_LAYER ? bi : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? ee->t : ee->t * nb + bi;
             DD_HIP(c, launch_ee_probe(m->x, m->probe_w + (long long)pi * D, m->probe_b + pi, ee->cls + (long long)bi * B, B, L, D, s));
@@ -399,12 +411,13 @@ int check_call(dd_ctx* c, dd_model* m, int B, const int64_t* y_dev) {
 }
 
 // one sampling step enqueued on s: x <- update(x, model(x, t)) ; t comes from ctx->st
+// advance != 0: the step's last kernel also decrements the device-resident timestep (graph replays / dd_sample)
 int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int noise_mode, const float* z_dev,
-                 int variance, float* eps_out, int B, hipStream_t s) {
+                 int variance, float* eps_out, int B, hipStream_t s, int advance = 0) {
     int rc = run_model(m, x_dev, nullptr, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, x_dev, z_dev, eps_out, x_dev, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance, advance};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -433,6 +446,21 @@ int dd_schedule_table(int which, float* out) {
         default: return DD_ERR_INVALID;
     }
     std::memcpy(out, src, 1000 * sizeof(float));
+    return DD_OK;
+}
+
+int dd_schedule_build(float beta_init, float beta_final, int steps, float* betas, float* alphas, float* alphas_bar,
+                      float* alphas_bar_prev, float* betas_tilde) {
+    if (steps < 1 || steps > (1 << 20)) return DD_ERR_INVALID;
+    std::vector<float> b(steps), a(steps), ab(steps), abp(steps);
+    base_tables(beta_init, beta_final, steps, b.data(), a.data(), ab.data(), abp.data());
+    const size_t bytes = (size_t)steps * sizeof(float);
+    if (betas) std::memcpy(betas, b.data(), bytes);
+    if (alphas) std::memcpy(alphas, a.data(), bytes);
+    if (alphas_bar) std::memcpy(alphas_bar, ab.data(), bytes);
+    if (alphas_bar_prev) std::memcpy(alphas_bar_prev, abp.data(), bytes);
+    if (betas_tilde)
+        for (int i = 0; i < steps; ++i) betas_tilde[i] = bt_scheduler_order(b[i], abp[i], ab[i]);
     return DD_OK;
 }
 
@@ -679,7 +707,7 @@ int dd_forward(dd_ctx* c, dd_model* m, const float* x_dev, float t, const float*
     rc = run_model(m, x_dev, t_dev, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -708,7 +736,7 @@ int dd_forward_early_exit(dd_ctx* c, dd_model* m, const float* x_dev, float t, c
     rc = run_model(m, x_dev, t_dev, y_dev, B, s, &ee);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps_dev, nullptr, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -737,12 +765,31 @@ int dd_ddpm_step(dd_ctx* c, const float* x_dev, const float* eps_dev, const floa
     return DD_OK;
 }
 
+int dd_ddpm_step_coef(dd_ctx* c, const float* x_dev, const float* eps_dev, const float* z_dev, float c1, float c2,
+                      float sigma, float* x_out_dev, int64_t n, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    if (!x_dev || !eps_dev || !x_out_dev || n < 0) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (n == 0) return DD_OK;
+    const StepCoef cf{c1, c2, sigma, sigma};
+    DD_HIP(c, launch_ddpm_step(x_dev, eps_dev, z_dev, x_out_dev, cf, z_dev ? 1 : 0, (long long)n, (hipStream_t)stream));
+    return DD_OK;
+}
+
 int dd_affine_step(dd_ctx* c, const float* x_dev, const float* m_dev, const float* z_dev, float a, float b, float cc,
                    float* out_dev, int64_t n, void* stream) {
     if (!c) return DD_ERR_INVALID;
     if (!x_dev || !m_dev || !out_dev || n < 0) return fail(c, DD_ERR_INVALID, "null tensor");
     if (n == 0) return DD_OK;
     DD_HIP(c, launch_affine_step(x_dev, m_dev, z_dev, out_dev, a, b, cc, (long long)n, (hipStream_t)stream));
+    return DD_OK;
+}
+
+int dd_to_images(dd_ctx* c, const float* x_dev, float* images_dev, int B, int C, int S, void* stream) {
+    if (!c) return DD_ERR_INVALID;
+    if (!x_dev || !images_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (B < 0 || C < 1 || S < 1) return fail(c, DD_ERR_INVALID, "bad image shape");
+    if (B == 0) return DD_OK;
+    DD_HIP(c, launch_to_images(x_dev, images_dev, B, C, S, (hipStream_t)stream));
     return DD_OK;
 }
 
@@ -781,11 +828,9 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         hipGraph_t g = nullptr;
         DD_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_step(c, m, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s);
-        hipError_t e1 = r ? hipSuccess : launch_advance_state(c->st, s);
+        int r = enqueue_step(c, m, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
         hipError_t e2 = hipStreamEndCapture(s, &g);
         if (r) { if (g) (void)hipGraphDestroy(g); return r; }
-        if (e1 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail_hip(c, e1, "advance_state"); }
         if (e2 != hipSuccess) return fail_hip(c, e2, "hipStreamEndCapture");
         hipError_t e3 = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
@@ -806,9 +851,8 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         if (a->use_graph) {
             DD_HIP(c, hipGraphLaunch(cur->graph, s));
         } else {
-            rc = enqueue_step(c, cur, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s);
+            rc = enqueue_step(c, cur, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
             if (rc) return rc;
-            DD_HIP(c, launch_advance_state(c->st, s));
         }
         if (switching && t == t_sw) {
             cur = a->late;

@@ -34,9 +34,11 @@ template <> struct Elem<bf16_t> {
 // Device-resident per-step state, so that a captured hipGraph replays without parameter
 // patching: kernels read t from here, the last node of a step decrements it.
 struct StepState {
-    int t;            // current timestep (999 .. 0)
+    int t;            // current timestep (999 .. 0): read by the FIRST kernel of a step (token assembly) only
     float t_model;    // what the model sees: t or t/1000 is derived in the embed kernel
     unsigned long long seed;
+    int t_final;      // copy of t made by the embed kernel and read by the LAST kernel of the step, which may then
+                      // decrement t / t_model for the next replay without racing its own blocks (no separate launch)
     int pad;
 };
 
@@ -82,7 +84,7 @@ struct EmbedArgs {
     const float* label_emb;  // [num_classes, D] or null
     const long long* y;      // [B] or null
     const float* t_vec;      // [B] per-row timesteps or null (then st->t_model)
-    const StepState* st;
+    StepState* st;           // t_model is read, t_final is written (block 0)
     float* x_tok;            // [Mp, D]
     int B, C, S, P, D, L, extras, num_classes, normalize, Mp;
 };
@@ -103,9 +105,10 @@ struct FinalArgs {
     const float* z;        // [B,C,S,S] or null
     float* eps_out;        // or null
     float* x_out;          // or null (may alias x_in)
-    const StepState* st;
+    StepState* st;         // reads t_final / seed; advance != 0: one thread sets t = t_final - 1 for the next step
     const StepCoef* coef;  // [1000]
     int B, C, S, P, L, extras, noise_mode, variance;
+    int advance;
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 
@@ -129,6 +132,7 @@ hipError_t launch_ee_select(const float* outs, const float* eps, const float* cl
                             float* mo, int* idx, float* err_mean, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
-hipError_t launch_advance_state(StepState* st, hipStream_t s);
+// (x + 1) / 2, NCHW -> NHWC: the output convention of reference sampler.py:145-146
+hipError_t launch_to_images(const float* x, float* out, int B, int C, int S, hipStream_t s);
 
 }  // namespace dd

@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedArgs a) {
     const int tid = threadIdx.x;
     const int pd = a.C * a.P * a.P;
     const int g = a.S / a.P;
+    if (blockIdx.x == 0 && tid == 0) a.st->t_final = a.st->t;   // handed to the step's last kernel (StepState)
 
     if (b >= a.B) {  // padding rows of the workspace
         const long long row0 = (long long)a.B * a.L + (long long)(blockIdx.x - a.B * rows_per_img_blocks) * kEmbedTok;
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
     const int b = blockIdx.x / chunks, r0 = (blockIdx.x % chunks) * TOK;
     const int tid = threadIdx.x;
     const int g = a.S / a.P, PP = a.P * a.P;
+    if (blockIdx.x == 0 && tid == 0) a.st->t_final = a.st->t;   // handed to the step's last kernel (StepState)
     if (b >= a.B) {  // padding rows of the workspace
         const long long row0 = (long long)a.B * a.L + (long long)(blockIdx.x - a.B * chunks) * TOK;
         for (int j = 0; j < TOK; ++j) {
@@ -310,7 +312,8 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
         }
     }
 
-    const int t = a.st->t;
+    const int t = a.st->t_final;
+    if (a.advance && pix == 0) { a.st->t = t - 1; a.st->t_model = (float)(t - 1); }   // no block of this kernel reads t / t_model
     const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
@@ -351,6 +354,11 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
     }
     __syncthreads();
     const int ly = tid >> 4, lx = tid & 15, y = ty * 16 + ly, x = tx * 16 + lx;
+    if (a.advance && blockIdx.x == 0 && tid == 0) {   // no block of this kernel reads t / t_model
+        const int tn = a.st->t_final - 1;
+        a.st->t = tn;
+        a.st->t_model = (float)tn;
+    }
     if (y >= S || x >= S) return;
     float acc[4];
 #pragma unroll
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
                     if (co < C) acc[co] = fmaf(a.wconv[((co * C + ci) * 3 + dy) * 3 + dx], uv, acc[co]);
             }
         }
-    const int t = a.st->t;
+    const int t = a.st->t_final;
     const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
@@ -415,17 +423,24 @@ __global__ void affine_step_kernel(const float* __restrict__ x, const float* __r
 
 __global__ void set_state_kernel(StepState* st, int t, unsigned long long seed) {
     st->t = t;
+    st->t_final = t;
     st->t_model = (float)t;
     st->seed = seed;
 }
 __global__ void set_state_float_kernel(StepState* st, float t) {
     st->t = (int)t;
+    st->t_final = (int)t;
     st->t_model = t;
 }
-__global__ void advance_state_kernel(StepState* st) {
-    const int t = st->t - 1;
-    st->t = t;
-    st->t_model = (float)t;
+
+// reference sampler.py:145-146: samples = rearrange((x + 1) / 2, "b c h w -> b h w c").  One thread per pixel: the NCHW
+// reads are coalesced per channel plane, the NHWC writes are C contiguous floats per thread.
+__global__ void __launch_bounds__(256) to_images_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int S) {
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long hw = (long long)S * S;
+    if (pix >= (long long)B * hw) return;
+    const long long b = pix / hw, p = pix - b * hw;
+    for (int c = 0; c < C; ++c) out[pix * C + c] = (x[(b * C + c) * hw + p] + 1.0f) / 2.0f;
 }
 
 // ---- early-exit baseline (reference models/early_exit.py, eesampler.py) --------------------------------------
@@ -575,8 +590,9 @@ hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s) {
     hipLaunchKernelGGL(set_state_float_kernel, dim3(1), dim3(1), 0, s, st, t);
     return hipGetLastError();
 }
-hipError_t launch_advance_state(StepState* st, hipStream_t s) {
-    hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, st);
+hipError_t launch_to_images(const float* x, float* out, int B, int C, int S, hipStream_t s) {
+    const long long npix = (long long)B * S * S;
+    hipLaunchKernelGGL(to_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, out, B, C, S);
     return hipGetLastError();
 }
 

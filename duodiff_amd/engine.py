@@ -80,6 +80,23 @@ class Context:
                                          _ptr(out), x.numel(), _stream_ptr(stream)))
         return out
 
+    def ddpm_step_coef(self, x, eps, z, c1, c2, sigma, out=None, stream=None):
+        """x' = c1 * (x - c2 * eps) + sigma * z with caller-supplied scalars (any schedule; ddpm_core.py:190-193)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        self.check(self.lib.dd_ddpm_step_coef(self.handle, _ptr(x), _ptr(eps.contiguous()),
+                                              _ptr(z.contiguous() if z is not None else None), float(c1), float(c2),
+                                              float(sigma), _ptr(out), x.numel(), _stream_ptr(stream)))
+        return out
+
+    def to_images(self, x, out=None, stream=None):
+        """(x + 1) / 2 as [B,H,W,C] (reference sampler.py:145-146), on the device."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[2] == x.shape[3]
+        B, Cc, S, _ = x.shape
+        out = torch.empty(B, S, S, Cc, device=x.device, dtype=torch.float32) if out is None else out
+        self.check(self.lib.dd_to_images(self.handle, _ptr(x), _ptr(out), B, Cc, S, _stream_ptr(stream)))
+        return out
+
     def early_exit_select(self, outputs, eps, classifier_outputs, threshold, stream=None):
         """eesampler.py:61-71 on device tensors -> (model_output [B,...], indices int32 [B], batch-mean errors [depth])."""
         depth, B = classifier_outputs.shape
@@ -136,6 +153,18 @@ def schedule_tables():
             raise RuntimeError(f"dd_schedule_table({i}) -> {rc}")
         out[n] = a
     return out
+
+
+def build_schedule(beta_init=1e-4, beta_final=0.02, beta_steps=1000):
+    """NoiseScheduler.__init__ tables (ddpm_core.py:56-70) for any schedule, from the engine's host arithmetic."""
+    lib = L.load()
+    n = int(beta_steps)
+    names = ["betas", "alphas", "alphas_bar", "alpha_bar_prev", "betas_tilde"]
+    arrs = [np.empty(n, np.float32) for _ in names]
+    rc = lib.dd_schedule_build(float(beta_init), float(beta_final), n, *[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
+    if rc != L.DD_OK:
+        raise ValueError(f"dd_schedule_build({beta_init}, {beta_final}, {beta_steps}) -> {rc}")
+    return dict(zip(names, arrs))
 
 
 class Model:

@@ -11,8 +11,8 @@ bit-identical noise for parity runs).
         --batch_size 128 --parametrization predict_noise --output_folder out
 
 DDIM (--use_ddim) and the predict_original / predict_previous parametrizations run
-the U-ViT forward on the engine plus one fused affine update per step.  Out of scope this round: the KL-VAE
-decode of ImageNet-256 latents (next-1).
+the U-ViT forward on the engine plus one fused affine update per step; ImageNet-256 latents are decoded by the
+engine's KL-VAE decoder when the YAML carries an ``autoencoder`` block (next-1).
 """
 import math
 import random
@@ -142,7 +142,11 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     first = model.engine_model(batch_size)
     late = late_model.engine_model(batch_size) if late_model is not None else None
     ctx = first.ctx
-    switch_t = 1000 - t_switch if (late is not None and np.isfinite(t_switch)) else None
+    # the DDPM loop switches AFTER the step at t == 1000 - t_switch (sampler.py:135-136): a t_switch outside
+    # [1, 1000] (0, negative, > 1000, inf) never matches a t in 999..0, i.e. the first model runs every step
+    switch_t = None
+    if late is not None and np.isfinite(t_switch) and 0 <= 1000 - int(t_switch) <= 999:
+        switch_t = 1000 - int(t_switch)
 
     def draw(shape):
         return torch.randn(shape).to(device) if noise == "torch_cpu" else torch.randn(shape, device=device)
@@ -208,8 +212,8 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
         print("Decode the images...")
         x = autoencoder.decode(x)
         intermediate = [autoencoder.decode(v) for v in intermediate]
-    samples = ((x + 1) / 2).permute(0, 2, 3, 1).contiguous()                 # :145-146
-    inter = [((v + 1) / 2).permute(0, 2, 3, 1).contiguous().cpu().numpy() for v in intermediate]
+    samples = ctx.to_images(x.contiguous())                                  # :145-146, library kernel
+    inter = [ctx.to_images(v.contiguous()).cpu().numpy() for v in intermediate]
     if return_device_tensor:
         return samples, inter
     return samples.cpu().numpy(), inter                                      # :155 (D2H boundary)

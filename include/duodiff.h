@@ -85,6 +85,12 @@ int dd_sync(dd_ctx* ctx, void* stream);
  * 8 sigma=sqrt(betas_tilde).  Works without a GPU (host arithmetic only). */
 int dd_schedule_table(int which, float* out1000);
 
+/* NoiseScheduler.__init__ (ddpm_core.py:56-70) for any (beta_init, beta_final, beta_steps): torch.linspace / cumprod
+ * restated bit for bit; betas_tilde in the ddpm_core rounding order.  Each output holds `steps` floats or is NULL.
+ * Host arithmetic only. */
+int dd_schedule_build(float beta_init, float beta_final, int steps, float* betas, float* alphas, float* alphas_bar,
+                      float* alphas_bar_prev, float* betas_tilde);
+
 /* ---- model: replaces UViT(**model_params) + load_state_dict (sampler.py:271-293) ---- */
 int dd_model_create(dd_ctx* ctx, const dd_config* cfg, dd_model** out);
 /* name = the reference state_dict key (models/uvit.py:228-336), data = host fp32,
@@ -130,11 +136,24 @@ int dd_early_exit_select(dd_ctx* ctx, const float* outputs_dev, const float* eps
 int dd_ddpm_step(dd_ctx* ctx, const float* x_dev, const float* eps_dev, const float* z_dev,
                  int t, int variance, float* x_out_dev, int64_t n, void* stream);
 
+/* The same update with the three scalars supplied by the caller: x' = c1 * (x - c2 * eps) + sigma * z (z_dev NULL: no
+ * noise term), rounded op by op like the reference.  For schedules other than the 1000-step default
+ * (NoiseScheduler(beta_steps=...), ddpm_core.py:167-193): the host derives c1 = sqrt(1/alpha_t),
+ * c2 = (1-alpha_t)/sqrt(1-alphas_bar_t), sigma = sqrt(sigma_squared_t) from dd_schedule_build's tables. */
+int dd_ddpm_step_coef(dd_ctx* ctx, const float* x_dev, const float* eps_dev, const float* z_dev, float c1, float c2,
+                      float sigma, float* x_out_dev, int64_t n, void* stream);
+
 /* ---- generic scalar-affine update: out = a*x + b*m + c*z (z_dev may be NULL) ---------- */
 /* The form shared by predict_original / predict_previous post-processing (sampler.py:59-79) and a
  * DDIM step (sampler.py:112-120); the host computes a, b, c from the schedule tables. */
 int dd_affine_step(dd_ctx* ctx, const float* x_dev, const float* m_dev, const float* z_dev, float a,
                    float b, float c, float* out_dev, int64_t n, void* stream);
+
+/* ---- samples = rearrange((x + 1) / 2, "b c h w -> b h w c")  (sampler.py:145-146) -------- */
+/* x_dev [B,C,S,S] fp32 -> images_dev [B,S,S,C] fp32, unclipped like the reference (quirk Q8).  Lets the whole
+ * timed region of get_samples (sampler.py:327-345) stay inside the library: no torch op between the last step
+ * and the D2H copy / the gather. */
+int dd_to_images(dd_ctx* ctx, const float* x_dev, float* images_dev, int B, int C, int S, void* stream);
 
 /* ---- one fused sampling step: x <- step(x, model(x,t,y), t) in place ---------------- */
 /* noise_mode DD_NOISE_BUFFER: z_dev [B,C,S,S] supplies z (parity with the torch CPU stream);

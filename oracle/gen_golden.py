@@ -177,12 +177,20 @@ def gen_rollout():
 
 
 def gen_scheduler():
+    """NoiseScheduler.sample (ddpm_core.py:106-214, uvit branch): a 50-step schedule in both variance modes and the
+    default 1000-step schedule (sigma^2 = beta, the class default), tiny model, CPU generator."""
     m, mp = build_ref(dict(TINY, depth=1), seed=400)
-    sch = ref_ddpm.NoiseScheduler(beta_steps=50)
-    with contextlib.redirect_stderr(io.StringIO()):
-        x0, log = sch.sample(m, num_steps=50, data_shape=(3, 8, 8), num_samples=2, seed=5, model_type="uvit")
-    np.savez(OUT / "scheduler_tiny.npz", x0=x0.numpy(), x_after_first=log["samples_over_time"][0].numpy(),
-             x_mid=log["samples_over_time"][25].numpy(), seed=np.array(400))
+    out = dict(seed=np.array(400))
+    for tag, steps, mode in (("", 50, "beta"), ("_bt50", 50, "beta_tilde"), ("_b1000", 1000, "beta")):
+        sch = ref_ddpm.NoiseScheduler(beta_steps=steps, variance_mode=mode)
+        with contextlib.redirect_stderr(io.StringIO()):
+            x0, log = sch.sample(m, num_steps=steps, data_shape=(3, 8, 8), num_samples=2, seed=5, model_type="uvit")
+            m.eval()   # sample() leaves the module in train mode (ddpm_core.py:213)
+        out["x0" + tag] = x0.numpy()
+        out["x_after_first" + tag] = log["samples_over_time"][0].numpy()
+        out["x_mid" + tag] = log["samples_over_time"][steps // 2].numpy()
+        assert all(np.isfinite(v).all() for k, v in out.items())
+    np.savez(OUT / "scheduler_tiny.npz", **out)
 
 
 def gen_full():
@@ -226,19 +234,31 @@ def gen_param():
 
 
 def gen_ddim():
-    """get_samples(use_ddim=True) with the tiny shallow+full pair (sampler.py:103-126)."""
+    """get_samples(use_ddim=True) with the tiny shallow+full pair (sampler.py:103-126).
+
+    The reference scales the DDIM noise by sigma^2 = betas_tilde[t]*eta and takes sqrt(1 - abar_s - sigma^2)
+    (sampler.py:112-120); with few steps and eta > 0 that square root goes negative at the last pair (s = 0) and the
+    samples are NaN.  Cases a-c are chosen so that every value is finite (asserted here and again in the tests);
+    case "nan" pins the quirk itself: the reference's output for (10 steps, eta 0.5) IS all-NaN.
+    """
     m_s, mp = build_ref(dict(TINY, depth=1), seed=300)
     m_f, _ = build_ref(dict(TINY, depth=3), seed=301)
     out = {}
-    for tag, steps, eta, tsw in (("a", 20, 0.0, 300), ("b", 10, 0.5, 600)):
-        with contextlib.redirect_stderr(io.StringIO()):
+    for tag, steps, eta, tsw in (("a", 20, 0.0, 300), ("b", 500, 0.5, 600), ("c", 10, 0.03, 600), ("nan", 10, 0.5, 600)):
+        with contextlib.redirect_stderr(io.StringIO()), np.errstate(invalid="ignore"):
             samples, inter = ref_sampler.get_samples(
                 model=m_s, batch_size=2, postprocessing=ref_sampler.predict_noise_postprocessing, seed=3,
                 num_channels=3, sample_height=8, sample_width=8, use_ddim=True, ddim_steps=steps, ddim_eta=eta,
                 timesteps_save=[1], y=None, autoencoder=None, late_model=m_f, t_switch=tsw)
+        out[f"cfg_{tag}"] = np.array([steps, eta, tsw], np.float64)
+        if tag == "nan":
+            out["nan_fraction"] = np.array(float(np.isnan(samples).mean()))
+            assert np.isfinite(inter[0]).all()
+            out["first_nan"] = inter[0]
+            continue
+        assert np.isfinite(samples).all() and np.isfinite(inter[0]).all(), tag
         out[f"samples_{tag}"] = samples
         out[f"first_{tag}"] = inter[0]
-        out[f"cfg_{tag}"] = np.array([steps, eta, tsw], np.float64)
     np.savez(OUT / "ddim_tiny.npz", **out)
 
 

@@ -26,8 +26,16 @@ def have_gpu():
 
 @pytest.fixture(scope="session")
 def golden():
+    """Loader for tests/golden/*.npz.  Every floating-point array of a fixture must be finite: a NaN expected value
+    would make assert_allclose (equal_nan=True by default) pass vacuously.  The reference's NaN quirks are pinned
+    through explicit scalar keys (e.g. ddim_tiny.npz::nan_fraction), never through NaN arrays."""
     def load(name):
-        return np.load(GOLDEN / name, allow_pickle=False)
+        fx = np.load(GOLDEN / name, allow_pickle=False)
+        for k in fx.files:
+            a = fx[k]
+            if np.issubdtype(a.dtype, np.floating):
+                assert np.isfinite(a).all(), f"{name}::{k} holds non-finite values"
+        return fx
     return load
 
 

@@ -40,8 +40,19 @@ def test_schedule_mirrors():
     s = NoiseScheduler()
     assert torch.equal(s.betas, sampler.schedule.betas) and s.sigma_squared() is s.betas
     assert NoiseScheduler(variance_mode="beta_tilde").sigma_squared().shape == (1000,)
-    with pytest.raises(ValueError):
-        NoiseScheduler(variance_mode="nope")
+    with pytest.raises(ValueError):                      # raised where the reference raises it (ddpm_core.py:72-79)
+        NoiseScheduler(variance_mode="nope").sigma_squared()
+    # any schedule: bit-equal to the oracle's restatement of ddpm_core.py:64-70 (pinned by schedule.npz at 1000 steps)
+    import oracle
+    for args in ((1e-4, 0.02, 50), (1e-4, 0.02, 1000), (3e-4, 0.05, 333), (1e-4, 0.02, 7)):
+        s = NoiseScheduler(*args, variance_mode="beta_tilde")
+        want = oracle.scheduler_schedule(*args)
+        for k in ("betas", "alphas", "alphas_bar", "alpha_bar_prev", "betas_tilde"):
+            assert np.array_equal(getattr(s, k).numpy(), want[k]), (args, k)
+        t = args[2] // 2
+        c1, c2, sg = s.step_coefficients(t)
+        o1, o2, o3 = oracle.schedule_oracle.step_coefficients(want, t, "beta_tilde")
+        assert (np.float32(c1), np.float32(c2), np.float32(sg)) == (o1, o2, o3)
 
 
 @pytest.mark.skipif(have_gpu(), reason="asserts the no-GPU failure mode")
