@@ -19,7 +19,7 @@ CSRC = PKG / "csrc"
 OBJ = REPO / "build" / "obj"
 LIB = PKG / "libduodiff.so"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", f"-I{REPO / 'include'}"]
 
 

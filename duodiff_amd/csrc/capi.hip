@@ -22,6 +22,7 @@ namespace dd {
 hipError_t init_gemm_kernels();
 hipError_t init_attention_kernels();
 hipError_t init_rowops_kernels();
+int gemm_num_cus();
 }  // namespace dd
 
 // ------------------------------------------------------------------------------------------
@@ -46,6 +47,8 @@ struct HostParam {
 struct BlockW {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *proj_b, *fc1_b, *fc2_b, *skip_b;
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w, *skip_w;
+    const char* mlp_img;     // fused-MLP weight image (mlp_fused.hip) or null
+    const float* mlp_b1p;    // fc1 bias in accumulator-register order
 };
 
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
@@ -79,6 +82,9 @@ struct dd_model {
     int ee_type = -1, n_probe = 0;
     std::vector<HeadW> heads;             // head i is applied to the input of block i
     const float *probe_w = nullptr, *probe_b = nullptr;   // [n_probe, D], [n_probe]
+    bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
+    float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
+    size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph = nullptr;
     GraphKey gkey{};
     // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
@@ -357,26 +363,39 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
         }
         DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));
-        {
-            GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hid_ld};
-            if (m->time_fc1) {
-                while (m->fc1_events.size() < m->fc1_used + 2) {
-                    hipEvent_t e;
-                    DD_HIP(c, hipEventCreate(&e));
-                    m->fc1_events.push_back(e);
-                }
-                DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used], s));
+        // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
+        // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
+        T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
+        auto mark = [&]() -> int {   // in-context timing of the dominant kernel (dd_profile_steps)
+            if (!m->time_fc1) return DD_OK;
+            while (m->fc1_events.size() < m->fc1_used + 1) {
+                hipEvent_t e;
+                DD_HIP(c, hipEventCreate(&e));
+                m->fc1_events.push_back(e);
             }
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s));
-            if (m->time_fc1) {
-                DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used + 1], s));
-                m->fc1_used += 2;
+            DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used++], s));
+            return DD_OK;
+        };
+        if constexpr (sizeof(T) == 2) {
+            if (m->fused_mlp) {
+                MlpFusedArgs fa{};
+                fa.X = (const bf16_t*)h; fa.ldx = D; fa.wimg = w.mlp_img; fa.b1p = w.mlp_b1p; fa.b2 = w.fc2_b;
+                fa.xres = m->x; fa.out = (bf16_t*)copy; fa.ldo = D; fa.partial = m->mlp_partial;
+                mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
+                if (int rc = mark()) return rc;
+                DD_HIP(c, launch_mlp_fused(fa, D, s));
+                if (int rc = mark()) return rc;
+                continue;
             }
         }
         {
-            // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
-            // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
-            T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
+            GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hid_ld};
+            const bool timed = !m->fused_mlp;
+            if (timed) if (int rc = mark()) return rc;
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s));
+            if (timed) if (int rc = mark()) return rc;
+        }
+        {
             GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
                           m->hid_ld, m->hid_ld, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
@@ -483,7 +502,7 @@ int dd_ctx_create(int device, dd_ctx** out) {
               hipMemset(c->st, 0, sizeof(StepState)) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
-         init_rowops_kernels() == hipSuccess;
+         init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess;
     if (!ok) { dd_ctx_destroy(c); return DD_ERR_HIP; }
     *out = c;
     return DD_OK;
@@ -594,7 +613,11 @@ int dd_model_finalize(dd_model* m, int precision) {
     };
     auto P = [&](const std::string& nm) -> const std::vector<float>& { return m->params[nm].data; };
 
-    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w; bool skip; };
+    // fused MLP (mlp_fused.hip): bf16 mode only; DD_FUSED_MLP=0 keeps the two-GEMM path (A/B runs)
+    const char* env_fused = std::getenv("DD_FUSED_MLP");
+    m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(env_fused && env_fused[0] == '0');
+    auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p; bool skip; };
     std::vector<BlockOff> boffs;
     auto pack_block = [&](const std::string& p, bool skip) {
         BlockOff o{};
@@ -606,6 +629,12 @@ int dd_model_finalize(dd_model* m, int precision) {
         o.qkv_w = put_mat(P(p + "attn.qkv.weight")); o.proj_w = put_mat(P(p + "attn.proj.weight"));
         o.fc1_w = put_mat(P(p + "mlp.fc1.weight")); o.fc2_w = put_mat(P(p + "mlp.fc2.weight"));
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
+        if (m->fused_mlp) {
+            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid));
+            o.mlp_b1p = put_raw((size_t)hid * 4);
+            mlp_fused_pack(D, hid, P(p + "mlp.fc1.weight").data(), P(p + "mlp.fc1.bias").data(), P(p + "mlp.fc2.weight").data(),
+                           host_f2bf, (unsigned short*)&host[o.mlp_img], (float*)&host[o.mlp_b1p]);
+        }
         boffs.push_back(o);
     };
     for (int i = 0; i < m->half_depth; ++i) pack_block("in_blocks." + std::to_string(i) + ".", false);
@@ -658,7 +687,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     for (const BlockOff& o : boffs) {
         BlockW w{F(o.ln1_g), F(o.ln1_b), F(o.ln2_g), F(o.ln2_b), F(o.proj_b), F(o.fc1_b), F(o.fc2_b),
                  o.skip ? F(o.skip_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
-                 o.skip ? V(o.skip_w) : nullptr};
+                 o.skip ? V(o.skip_w) : nullptr, m->fused_mlp ? (const char*)V(o.mlp_img) : nullptr,
+                 m->fused_mlp ? F(o.mlp_b1p) : nullptr};
         m->blocks.push_back(w);
     }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
@@ -675,11 +705,15 @@ int dd_model_finalize(dd_model* m, int precision) {
     std::vector<size_t> o_sk;
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
     const size_t o_dec = take(Mp * m->pd * 4);
+    const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid) : 0;
+    const size_t o_part = take(part_bytes);
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
     m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
     m->hid = m->wsarena + o_hid; m->xb = m->wsarena + o_xb; m->dec = (float*)(m->wsarena + o_dec);
     for (size_t o : o_sk) m->skips.push_back(m->wsarena + o);
+    m->mlp_partial = part_bytes ? (float*)(m->wsarena + o_part) : nullptr;
+    m->mlp_partial_bytes = part_bytes;
 
     // host copies are no longer needed
     for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
@@ -932,6 +966,57 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_out = ms / (float)iters;
     if (flops_out) *flops_out = 2.0 * (double)M * (double)m->hidden * (double)D;
+    return DD_OK;
+}
+
+int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_host, const float* w1, const float* b1, const float* w2,
+               const float* b2, float* xres_host, unsigned short* out_host, int iters, void* stream, float* ms_out) {
+    if (!c || !x_host || !w1 || !b1 || !w2 || !b2 || !xres_host || M < 1 || iters < 0 || extras < 0 || (extras > 0 && M % (1 + extras))) return DD_ERR_INVALID;
+    if (!mlp_fused_supported(D, hidden)) return fail(c, DD_ERR_UNSUPPORTED, "fused MLP: D in {64,128,256,512}, hidden % 64 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t Mp = (size_t)round_up(M, 256);
+    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden) / 2, 0);
+    std::vector<float> b1p(hidden), xr(Mp * D, 0.f);
+    for (size_t i = 0; i < (size_t)M * D; ++i) { xh[i] = host_f2bf(x_host[i]); xr[i] = xres_host[i]; }
+    mlp_fused_pack(D, hidden, w1, b1, w2, host_f2bf, img.data(), b1p.data());
+    // extras > 0: the M rows are `M / (1 + extras)` images of one patch token each (drives the hidden-split path);
+    // extras == 0: one image of M patch tokens (main tiles only)
+    MlpFusedArgs a{};
+    if (extras > 0) mlp_fused_plan(M / (1 + extras), 1, extras, 1 + extras, hidden, a);
+    else mlp_fused_plan(1, M, 0, M, hidden, a);
+    const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
+    void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP}) if (p) (void)hipFree(p); };
+#define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
+    DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
+    DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
+    if (part) DD_TRY(hipMalloc(&dP, part));
+    DD_TRY(hipMemcpy(dX, xh.data(), xh.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dI, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dB1, b1p.data(), hidden * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dB2, b2, D * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dXr, xr.data(), xr.size() * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemset(dO, 0, xh.size() * 2));
+    a.X = (const bf16_t*)dX; a.ldx = D; a.wimg = (const char*)dI; a.b1p = (const float*)dB1; a.b2 = (const float*)dB2;
+    a.xres = (float*)dXr; a.out = out_host ? (bf16_t*)dO : nullptr; a.ldo = D; a.partial = (float*)dP;
+    DD_TRY(launch_mlp_fused(a, D, s));
+    DD_TRY(hipStreamSynchronize(s));
+    DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));
+    if (out_host) DD_TRY(hipMemcpy(out_host, dO, (size_t)M * D * 2, hipMemcpyDeviceToHost));
+    if (iters > 0 && ms_out) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
+        DD_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) DD_TRY(launch_mlp_fused(a, D, s));
+        DD_TRY(hipEventRecord(e1, s));
+        DD_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DD_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_out = ms / (float)iters;
+    }
+#undef DD_TRY
+    cleanup();
     return DD_OK;
 }
 

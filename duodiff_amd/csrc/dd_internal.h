@@ -76,6 +76,32 @@ void set_gemm_num_cus(int n);
 bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e);
 int get_gemm_variant();
 
+// ---- fused MLP (mlp_fused.hip): x += fc2(gelu(fc1(h) + b1)) + b2 in one launch
+struct MlpFusedArgs {
+    const bf16_t* X;       // [Mp, ldx] LayerNorm output h (bf16)
+    int ldx;
+    const char* wimg;      // weight image in MFMA fragment order (mlp_fused_pack)
+    const float* b1p;      // fc1 bias, permuted to accumulator-register order per chunk
+    const float* b2;       // [D]
+    float* xres;           // fp32 [Mp, D] residual stream, updated in place
+    bf16_t* out;           // optional bf16 copy of the updated rows, row stride ldo
+    int ldo;
+    float* partial;        // partial slabs of the hidden-split leftover tiles
+    int nchunks;           // hidden / 32
+    // row plan (mlp_fused_plan): token row of image b, token l = b * tok_l + l; tokens [0, tok_e) are the extras, then tok_n patches
+    int tok_n, tok_e, tok_l;
+    int n_main, n_extra;   // B * tok_n patch rows (main tiles), B * tok_e extra rows (hidden-split tiles)
+    int tiles_main, tiles_left, groups, cpg;
+};
+bool mlp_fused_supported(int D, int hidden);
+size_t mlp_fused_image_bytes(int D, int hidden);
+size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
+void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
+void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2,
+                    unsigned short (*to_bf16)(float), unsigned short* img, float* b1p);
+hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
+hipError_t init_mlp_fused_kernels();
+
 struct EmbedArgs {
     const float* x_img;      // [B,C,S,S]
     const float* wt;         // [pd, D]  patch-embed weight, transposed

@@ -779,6 +779,7 @@ bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e) {
 }
 void set_gemm_num_cus(int n) { if (n >= 8) g_num_cus = n / 8 * 8; }
 int get_gemm_variant() { return g_variant_bf16; }
+int gemm_num_cus() { return g_num_cus; }
 
 template <typename T>
 hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s) {

@@ -210,6 +210,12 @@ int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_de
  * differ bitwise from variant 0 (all variants accumulate k in the same order), or -1 if check==0. */
 int dd_dev_gemm(dd_ctx* ctx, int M, int N, int K, int variant, int epilogue, int iters, int check,
                 void* stream, float* ms_out, long long* mismatch_out);
+/* Development harness for the fused MLP kernel: x += fc2(gelu(fc1(bf16(h)) + b1)) + b2 on host arrays (h [M,D], nn.Linear
+ * weights fp32, xres_host [M,D] in/out, out_host optional bf16 copy), plus `iters` timed launches.  extras == 0: the
+ * rows are one image of M patch tokens; extras > 0: M / (1 + extras) images of `extras` extra tokens + 1 patch token. */
+int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* xres_host, unsigned short* out_host, int iters, void* stream,
+               float* ms_out);
 /* Select the GEMM variant the engine uses for bf16 models (default 0). */
 int dd_set_gemm_variant(dd_ctx* ctx, int variant);
 
