@@ -67,7 +67,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dd_dev_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                               C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
-    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_plan_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -328,6 +328,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
 
     T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
     const int nb = (int)m->blocks.size();
+    bool h_ready = false;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one)
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
@@ -352,7 +353,8 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s));
         }
-        DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));
+        if (!h_ready) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
+        h_ready = false;
         {
             GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, nullptr, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
             DD_HIP(c, launch_gemm<T>(g, EPI_STORE, s));
@@ -362,7 +364,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
         }
-        DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));
+        if (!(sizeof(T) == 2 && m->fused_mlp)) DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));   // fused MLP: norm2 in its prologue
         // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
         // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
         T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
@@ -379,7 +381,12 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         if constexpr (sizeof(T) == 2) {
             if (m->fused_mlp) {
                 MlpFusedArgs fa{};
-                fa.X = (const bf16_t*)h; fa.ldx = D; fa.wimg = w.mlp_img; fa.b1p = w.mlp_b1p; fa.b2 = w.fc2_b;
+                fa.X = nullptr; fa.ldx = D; fa.wimg = w.mlp_img; fa.b1p = w.mlp_b1p; fa.b2 = w.fc2_b;
+                fa.ln_in_g = w.ln2_g; fa.ln_in_b = w.ln2_b;                       // norm2 of this block, in the prologue
+                if (bi + 1 < nb && bi + 1 <= m->half_depth) {                    // next block starts with norm1 (no skip_linear in between)
+                    fa.ln_out_g = m->blocks[bi + 1].ln1_g; fa.ln_out_b = m->blocks[bi + 1].ln1_b; fa.ln_out = (bf16_t*)h;
+                    h_ready = true;
+                }
                 fa.xres = m->x; fa.out = (bf16_t*)copy; fa.ldo = D; fa.partial = m->mlp_partial;
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
                 if (int rc = mark()) return rc;
@@ -633,7 +640,7 @@ int dd_model_finalize(dd_model* m, int precision) {
             o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid));
             o.mlp_b1p = put_raw((size_t)hid * 4);
             mlp_fused_pack(D, hid, P(p + "mlp.fc1.weight").data(), P(p + "mlp.fc1.bias").data(), P(p + "mlp.fc2.weight").data(),
-                           host_f2bf, (unsigned short*)&host[o.mlp_img], (float*)&host[o.mlp_b1p]);
+                           true, host_f2bf, (unsigned short*)&host[o.mlp_img], (float*)&host[o.mlp_b1p]);
         }
         boffs.push_back(o);
     };
@@ -970,7 +977,8 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
 }
 
 int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_host, const float* w1, const float* b1, const float* w2,
-               const float* b2, float* xres_host, unsigned short* out_host, int iters, void* stream, float* ms_out) {
+               const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in, const float* ln_out,
+               unsigned short* ln_out_host, int iters, void* stream, float* ms_out) {
     if (!c || !x_host || !w1 || !b1 || !w2 || !b2 || !xres_host || M < 1 || iters < 0 || extras < 0 || (extras > 0 && M % (1 + extras))) return DD_ERR_INVALID;
     if (!mlp_fused_supported(D, hidden)) return fail(c, DD_ERR_UNSUPPORTED, "fused MLP: D in {64,128,256,512}, hidden % 64 == 0");
     hipStream_t s = (hipStream_t)stream;
@@ -978,15 +986,16 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden) / 2, 0);
     std::vector<float> b1p(hidden), xr(Mp * D, 0.f);
     for (size_t i = 0; i < (size_t)M * D; ++i) { xh[i] = host_f2bf(x_host[i]); xr[i] = xres_host[i]; }
-    mlp_fused_pack(D, hidden, w1, b1, w2, host_f2bf, img.data(), b1p.data());
+    mlp_fused_pack(D, hidden, w1, b1, w2, ln_in != nullptr, host_f2bf, img.data(), b1p.data());
     // extras > 0: the M rows are `M / (1 + extras)` images of one patch token each (drives the hidden-split path);
     // extras == 0: one image of M patch tokens (main tiles only)
     MlpFusedArgs a{};
     if (extras > 0) mlp_fused_plan(M / (1 + extras), 1, extras, 1 + extras, hidden, a);
     else mlp_fused_plan(1, M, 0, M, hidden, a);
+    if (std::getenv("DD_DEV_MLP_EXTRAS_ONLY")) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
-    void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr;
-    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP}) if (p) (void)hipFree(p); };
+    void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH}) if (p) (void)hipFree(p); };
 #define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
     DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
     DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
@@ -997,12 +1006,22 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     DD_TRY(hipMemcpy(dB2, b2, D * 4, hipMemcpyHostToDevice));
     DD_TRY(hipMemcpy(dXr, xr.data(), xr.size() * 4, hipMemcpyHostToDevice));
     DD_TRY(hipMemset(dO, 0, xh.size() * 2));
+    // ln_in / ln_out: [2, D] gamma then beta of the LayerNorm fused into the prologue / epilogue (or NULL)
+    DD_TRY(hipMalloc(&dLn, (size_t)4 * D * 4));
+    DD_TRY(hipMalloc(&dH, xh.size() * 2));
+    DD_TRY(hipMemset(dH, 0, xh.size() * 2));
+    if (ln_in) { DD_TRY(hipMemcpy(dLn, ln_in, (size_t)2 * D * 4, hipMemcpyHostToDevice)); a.ln_in_g = (const float*)dLn; a.ln_in_b = (const float*)dLn + D; }
+    if (ln_out && ln_out_host) {
+        DD_TRY(hipMemcpy((float*)dLn + 2 * D, ln_out, (size_t)2 * D * 4, hipMemcpyHostToDevice));
+        a.ln_out_g = (const float*)dLn + 2 * D; a.ln_out_b = (const float*)dLn + 3 * D; a.ln_out = (bf16_t*)dH;
+    }
     a.X = (const bf16_t*)dX; a.ldx = D; a.wimg = (const char*)dI; a.b1p = (const float*)dB1; a.b2 = (const float*)dB2;
     a.xres = (float*)dXr; a.out = out_host ? (bf16_t*)dO : nullptr; a.ldo = D; a.partial = (float*)dP;
     DD_TRY(launch_mlp_fused(a, D, s));
     DD_TRY(hipStreamSynchronize(s));
     DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));
     if (out_host) DD_TRY(hipMemcpy(out_host, dO, (size_t)M * D * 2, hipMemcpyDeviceToHost));
+    if (a.ln_out) DD_TRY(hipMemcpy(ln_out_host, dH, (size_t)M * D * 2, hipMemcpyDeviceToHost));
     if (iters > 0 && ms_out) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));

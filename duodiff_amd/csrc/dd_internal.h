@@ -78,8 +78,13 @@ int get_gemm_variant();
 
 // ---- fused MLP (mlp_fused.hip): x += fc2(gelu(fc1(h) + b1)) + b2 in one launch
 struct MlpFusedArgs {
-    const bf16_t* X;       // [Mp, ldx] LayerNorm output h (bf16)
+    const bf16_t* X;       // [Mp, ldx] LayerNorm output h (bf16); unused when ln_in_g is set
     int ldx;
+    const float* ln_in_g;  // set: the kernel computes LayerNorm(x) * ln_in_g + ln_in_b itself from the residual rows
+    const float* ln_in_b;  //      (the W1 image must then be packed with kperm = true)
+    const float* ln_out_g; // with ln_out: LayerNorm of the UPDATED rows, written as bf16 [Mp, D] (next block's norm1)
+    const float* ln_out_b;
+    bf16_t* ln_out;
     const char* wimg;      // weight image in MFMA fragment order (mlp_fused_pack)
     const float* b1p;      // fc1 bias, permuted to accumulator-register order per chunk
     const float* b2;       // [D]
@@ -97,7 +102,7 @@ bool mlp_fused_supported(int D, int hidden);
 size_t mlp_fused_image_bytes(int D, int hidden);
 size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
-void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2,
+void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
                     unsigned short (*to_bf16)(float), unsigned short* img, float* b1p);
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t init_mlp_fused_kernels();

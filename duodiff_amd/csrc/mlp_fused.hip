@@ -58,17 +58,6 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {   // v_cvt_pk_bf
 //   * an MFMA result is not read by VALU code for 12 wait states (mfma_drain) unless a long MFMA sequence intervenes.
 // Accumulators: Y tiles "+a" (AGPR half of the register file: 256 registers at D = 512, resident for the whole kernel),
 // hidden-chunk accumulators "+v" (the GELU reads them with VALU instructions).
-template <int LGKM, bool NOP>
-__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    if constexpr (NOP)
-        asm volatile("s_waitcnt lgkmcnt(%3)\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(LGKM));
-    else
-        asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(LGKM));
-}
-template <int LGKM>
-__device__ __forceinline__ void mfma_hid(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(LGKM));
-}
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 template <int OFF>
 __device__ __forceinline__ void lds_frag(bf16x8& dst, unsigned addr) {
@@ -85,33 +74,78 @@ __device__ __forceinline__ void lds_quad(f32x4& dst, unsigned addr) {
 // one in front of it), cut into 8 pieces of 3 VALU instructions; one piece sits in the gap behind one MFMA.
 struct GeluConst { float hi, c5; };   // 3.8 and the s^12 coefficient live in VGPRs (VOP3 / fmamk take no second literal)
 struct GeluPair { float sa, s2a, pa, ha, sb, s2b, pb, hb; };
+
+// ONE gap of the instruction stream as ONE asm statement:
+//     s_waitcnt lgkmcnt(LG) ; MFMA ; [ds_read_b128 of the fragment PD steps ahead, into the register the MFMA just read]
+//     ; [piece K of the GELU pair (va, vb)]
+// KIND 0: S^T += W1 fragment . X^T, accumulator in VGPRs;  KIND 1: Y^T tile += W2 fragment . P^T, accumulator in AGPRs.
+// Every operand is declared for every variant (unused ones cost nothing); the GELU registers are read-write throughout.
+#define DD_S_MFMA "s_waitcnt lgkmcnt(%[lg])\n\tv_mfma_f32_32x32x16_bf16 %[acc], %[wa], %[xb], %[acc]"
+#define DD_S_READ "\n\tds_read_b128 %[wa], %[la] offset:%[lo]"
+#define DD_S_G0 "\n\tv_med3_f32 %[sa], %[va], %[kn], %[kh]\n\tv_med3_f32 %[sb], %[vb], %[kn], %[kh]\n\tv_mul_f32 %[s2a], %[sa], %[sa]"
+#define DD_S_G1 "\n\tv_mul_f32 %[s2b], %[sb], %[sb]\n\tv_fmamk_f32 %[pa], %[s2a], 0x339d7172, %[kc]\n\tv_fmamk_f32 %[pb], %[s2b], 0x339d7172, %[kc]"
+#define DD_S_G2 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x38fe87ac\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x38fe87ac\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xbaf43309"
+#define DD_S_G3 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xbaf43309\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3c98a4c9\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3c98a4c9"
+#define DD_S_G4 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xbe069818\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xbe069818\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3f4c1f5c"
+#define DD_S_G5 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3f4c1f5c\n\tv_mul_f32 %[pa], %[pa], %[sa]\n\tv_mul_f32 %[pb], %[pb], %[sb]"
+#define DD_S_G6 "\n\tv_mul_f32 %[ha], 0.5, %[va]\n\tv_mul_f32 %[hb], 0.5, %[vb]\n\tv_fmac_f32 %[ha], %[ha], %[pa]"
+#define DD_S_G7 "\n\tv_fmac_f32 %[hb], %[hb], %[pb]\n\tv_cvt_pk_bf16_f32 %[out], %[ha], %[hb]"
+#define DD_GAP_ASM(STR, ACC_C)                                                                                          \
+    asm volatile(STR                                                                                                    \
+                 : [acc] ACC_C(acc), [wa] "+v"(wa), [sa] "+v"(r.sa), [s2a] "+v"(r.s2a), [pa] "+v"(r.pa), [ha] "+v"(r.ha),  \
+                   [sb] "+v"(r.sb), [s2b] "+v"(r.s2b), [pb] "+v"(r.pb), [hb] "+v"(r.hb), [out] "+v"(out)                 \
+                 : [xb] "v"(xb), [la] "v"(la), [va] "v"(va), [vb] "v"(vb), [kn] "s"(-3.8f), [kh] "v"(k.hi), [kc] "v"(k.c5), \
+                   [lg] "i"(LG), [lo] "i"(LO))
+#define DD_GAP_K(KK, GSTR, ACC_C)                                              \
+    else if constexpr (K == KK) {                                             \
+        if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ GSTR, ACC_C);      \
+        else DD_GAP_ASM(DD_S_MFMA GSTR, ACC_C);                               \
+    }
+template <int KIND, int LG, bool READ, int LO, int K>
+__device__ __forceinline__ void gap_stmt(f32x16& acc, bf16x8& wa, const bf16x8& xb, unsigned la, float va, float vb,
+                                         const GeluConst& k, GeluPair& r, unsigned& out) {
+    if constexpr (KIND == 0) {
+        if constexpr (K < 0) {
+            if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ, "+v");
+            else DD_GAP_ASM(DD_S_MFMA, "+v");
+        }
+        DD_GAP_K(0, DD_S_G0, "+v") DD_GAP_K(1, DD_S_G1, "+v") DD_GAP_K(2, DD_S_G2, "+v") DD_GAP_K(3, DD_S_G3, "+v")
+        DD_GAP_K(4, DD_S_G4, "+v") DD_GAP_K(5, DD_S_G5, "+v") DD_GAP_K(6, DD_S_G6, "+v") DD_GAP_K(7, DD_S_G7, "+v")
+    } else {
+        if constexpr (K < 0) {
+            if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ, "+a");
+            else DD_GAP_ASM(DD_S_MFMA, "+a");
+        }
+        DD_GAP_K(0, DD_S_G0, "+a") DD_GAP_K(1, DD_S_G1, "+a") DD_GAP_K(2, DD_S_G2, "+a") DD_GAP_K(3, DD_S_G3, "+a")
+        DD_GAP_K(4, DD_S_G4, "+a") DD_GAP_K(5, DD_S_G5, "+a") DD_GAP_K(6, DD_S_G6, "+a") DD_GAP_K(7, DD_S_G7, "+a")
+    }
+}
+
+// the same GELU pieces as statements of their own (D < 512: several pieces per gap)
 template <int K>
 __device__ __forceinline__ void gelu_piece(float va, float vb, const GeluConst& k, GeluPair& r, unsigned& out) {
-    if constexpr (K == 0)
-        asm volatile("v_med3_f32 %0, %3, %5, %6\n\tv_med3_f32 %1, %4, %5, %6\n\tv_mul_f32 %2, %0, %0"
-                     : "=&v"(r.sa), "=&v"(r.sb), "=&v"(r.s2a) : "v"(va), "v"(vb), "s"(-3.8f), "v"(k.hi));
-    else if constexpr (K == 1)     //  7.331517960e-08 * s2 + c5
-        asm volatile("v_mul_f32 %0, %3, %3\n\tv_fmamk_f32 %1, %4, 0x339d7172, %5\n\tv_fmamk_f32 %2, %0, 0x339d7172, %5"
-                     : "=&v"(r.s2b), "=&v"(r.pa), "=&v"(r.pb) : "v"(r.sb), "v"(r.s2a), "v"(k.c5));
-    else if constexpr (K == 2)     //  * s2 + 1.213693460e-04 ; a: * s2 - 1.863093246e-03
-        asm volatile("v_fmaak_f32 %0, %0, %2, 0x38fe87ac\n\tv_fmaak_f32 %1, %1, %3, 0x38fe87ac\n\tv_fmaak_f32 %0, %0, %2, 0xbaf43309"
-                     : "+v"(r.pa), "+v"(r.pb) : "v"(r.s2a), "v"(r.s2b));
-    else if constexpr (K == 3)     //  b: * s2 - 1.863093246e-03 ; * s2 + 1.863326334e-02
-        asm volatile("v_fmaak_f32 %1, %1, %3, 0xbaf43309\n\tv_fmaak_f32 %0, %0, %2, 0x3c98a4c9\n\tv_fmaak_f32 %1, %1, %3, 0x3c98a4c9"
-                     : "+v"(r.pa), "+v"(r.pb) : "v"(r.s2a), "v"(r.s2b));
-    else if constexpr (K == 4)     //  * s2 - 1.314395642e-01 ; a: * s2 + 7.973534865e-01
-        asm volatile("v_fmaak_f32 %0, %0, %2, 0xbe069818\n\tv_fmaak_f32 %1, %1, %3, 0xbe069818\n\tv_fmaak_f32 %0, %0, %2, 0x3f4c1f5c"
-                     : "+v"(r.pa), "+v"(r.pb) : "v"(r.s2a), "v"(r.s2b));
-    else if constexpr (K == 5)     //  b: * s2 + 7.973534865e-01 ; e = P * s
-        asm volatile("v_fmaak_f32 %1, %1, %2, 0x3f4c1f5c\n\tv_mul_f32 %0, %0, %3\n\tv_mul_f32 %1, %1, %4"
-                     : "+v"(r.pa), "+v"(r.pb) : "v"(r.s2b), "v"(r.sa), "v"(r.sb));
-    else if constexpr (K == 6)     //  hv ; a: hv + hv * e
-        asm volatile("v_mul_f32 %0, 0.5, %2\n\tv_mul_f32 %1, 0.5, %3\n\tv_fmac_f32 %0, %0, %4"
-                     : "=&v"(r.ha), "=&v"(r.hb) : "v"(va), "v"(vb), "v"(r.pa));
-    else                           //  b: hv + hv * e ; pack the pair
-        asm volatile("v_fmac_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %0, %2, %1"
-                     : "=&v"(out), "+v"(r.hb) : "v"(r.ha), "v"(r.pb));
+    if constexpr (K == 0) asm volatile(DD_S_G0 : [sa] "+v"(r.sa), [sb] "+v"(r.sb), [s2a] "+v"(r.s2a) : [va] "v"(va), [vb] "v"(vb), [kn] "s"(-3.8f), [kh] "v"(k.hi));
+    else if constexpr (K == 1) asm volatile(DD_S_G1 : [s2b] "+v"(r.s2b), [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [sb] "v"(r.sb), [s2a] "v"(r.s2a), [kc] "v"(k.c5));
+    else if constexpr (K == 2) asm volatile(DD_S_G2 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
+    else if constexpr (K == 3) asm volatile(DD_S_G3 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
+    else if constexpr (K == 4) asm volatile(DD_S_G4 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
+    else if constexpr (K == 5) asm volatile(DD_S_G5 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2b] "v"(r.s2b), [sa] "v"(r.sa), [sb] "v"(r.sb));
+    else if constexpr (K == 6) asm volatile(DD_S_G6 : [ha] "+v"(r.ha), [hb] "+v"(r.hb) : [va] "v"(va), [vb] "v"(vb), [pa] "v"(r.pa));
+    else asm volatile(DD_S_G7 : [out] "+v"(out), [hb] "+v"(r.hb) : [ha] "v"(r.ha), [pb] "v"(r.pb));
 }
+
+// 16-byte global load straight into accumulator registers (AGPRs are legal vector-memory destinations on gfx950): the 64
+// loads of a lane's row are all in flight at once without holding a single VGPR.  hipcc does not count asm loads: the
+// caller waits (vmcnt) and fences the destinations before using them.
+template <int OFF>
+__device__ __forceinline__ void load_quad_agpr(f32x4& q, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(q) : "v"(p), "i"(OFF));
+}
+
+// Pin an accumulator tile to its AGPRs at this point of the program: hipcc treats the tile as rewritten, so VGPR copies
+// made for the LayerNorm / epilogue arithmetic die here instead of piling up (256 live values would spill to scratch).
+__device__ __forceinline__ void acc_pin(f32x16& y) { asm volatile("" : "+a"(y)); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
@@ -125,46 +159,39 @@ struct MlpCfg {
     static constexpr int FPW = F / 4;          // fragments each of the 4 waves DMAs per block
 };
 
-template <int D>
-__global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
+template <int D, bool LNIN, bool PARTIAL>
+__device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* b1s = reinterpret_cast<float*>(smem + C::RING);      // [hidden], in accumulator-register order per chunk
+    float* b1s = reinterpret_cast<float*>(smem + C::RING);           // [hidden + 32], in accumulator-register order per chunk
+    float* vecs = b1s + (a.nchunks + 1) * 32;                        // 5 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r32 = lane & 31;
 
-    // ---- which rows, which hidden chunks
-    int tile, c0, c1, slab = 0;
-    bool partial = false;
-    if ((int)blockIdx.x < a.tiles_main) {
-        tile = blockIdx.x; c0 = 0; c1 = a.nchunks;
-    } else {
-        const int e = blockIdx.x - a.tiles_main;
-        const int lt = e / a.groups, g = e - lt * a.groups;
-        tile = a.tiles_main + lt;
-        c0 = g * a.cpg;
-        c1 = c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks;
-        slab = e;
-        partial = true;
-    }
-    // logical row of this lane -> physical token row (clamped to a valid row; stores are masked by row_ok)
-    long long row;
-    bool row_ok;
-    {
-        const int idx = (partial ? tile - a.tiles_main : tile) * 128 + wave * 32 + r32;
-        if (!partial) {
-            row_ok = idx < a.n_main;
-            const int p = row_ok ? idx : 0, b = p / a.tok_n;
-            row = (long long)b * a.tok_l + a.tok_e + (p - b * a.tok_n);
+    // logical row of this lane -> physical token row (clamped to a valid row; stores are masked by row_ok).  Evaluated
+    // once for the prologue and again for the epilogue from an opaque copy of the lane id: kept live across the chunk
+    // loop these values (and the per-lane pointers derived from them) are what tips the loop over 256 VGPRs into spills.
+    auto row_of = [&](bool& ok) -> long long {
+        unsigned l = (unsigned)threadIdx.x;
+        asm volatile("" : "+v"(l));
+        const int idx = tile_idx * 128 + (int)l / 64 * 32 + ((int)l & 31);
+        if constexpr (!PARTIAL) {
+            ok = idx < a.n_main;
+            const int p = ok ? idx : 0, b = p / a.tok_n;
+            return (long long)b * a.tok_l + a.tok_e + (p - b * a.tok_n);
         } else {
-            row_ok = idx < a.n_extra;
-            const int q = row_ok ? idx : 0, b = q / a.tok_e;
-            row = (long long)b * a.tok_l + (q - b * a.tok_e);
+            ok = idx < a.n_extra;
+            const int q = ok ? idx : 0, b = q / a.tok_e;
+            return (long long)b * a.tok_l + (q - b * a.tok_e);
         }
-    }
+    };
+    auto half_of = [&]() -> int {     // lane >> 5, opaque (same reason)
+        unsigned l = (unsigned)threadIdx.x;
+        asm volatile("" : "+v"(l));
+        return (int)(l >> 5) & 1;
+    };
 
     // ---- LDS-DMA of one ring block.  Stream position b: chunk b>>1, W1 block if b is even, W2 block if odd.
     auto dma_block = [&](int b, int slot) {
@@ -184,20 +211,117 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
         for (int i = tid; i < C::BLK / 16; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    bf16x8 xf[C::KS];
-    {
-        const bf16_t* xr = a.X + row * a.ldx + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
-    }
     for (int i = tid; i < a.nchunks * 8; i += 256)
         reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(a.b1p)[i];
+    {   // per-column vectors -> LDS: the LayerNorm / epilogue arithmetic reads them as broadcast ds_read_b128 (every lane of a
+        // half wants the same 16 bytes), not as 300+ vector-memory instructions per lane
+        const float* src[5] = {a.ln_in_g, a.ln_in_b, a.ln_out_g, a.ln_out_b, a.b2};
+#pragma unroll
+        for (int v = 0; v < 5; ++v)
+            if (src[v])
+                for (int i = tid; i < D / 4; i += 256)
+                    reinterpret_cast<f32x4*>(vecs + v * D)[i] = reinterpret_cast<const f32x4*>(src[v])[i];
+    }
+    const float* lg_in = vecs + 4 * h;                 // this lane's column offset inside a quad pair
+    const float* lb_in = vecs + D + 4 * h;
+    bool row_ok_pro;
+    const long long row_pro = row_of(row_ok_pro);
 
+    bf16x8 xf[C::KS];
     f32x16 Y[C::NT];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (!LNIN) {
+        const bf16_t* xr = a.X + row_pro * a.ldx + 8 * h;
 #pragma unroll
-    for (int t = 0; t < C::NT; ++t)
+        for (int ks = 0; ks < C::KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Y[t][e] = 0.f;
+        for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[t][e] = 0.f;
+        __syncthreads();   // (vmcnt(0): the prologue blocks have landed; bias table, vectors and zero block are visible)
+    } else {
+        // x rows in accumulator layout: register quad g of tile t = columns 32t + 8g + 4h .. +3 of the lane's row.
+        // Main tiles keep x in the accumulators (the MLP output is added on top: no second read of x); hidden-split
+        // tiles zero them after the normalisation (x is added once, by the reduce kernel).
+        // This code runs at one wave per SIMD with nothing to hide latency behind: its length is its cost.
+        const float* xr = a.xres + row_pro * D + 4 * h;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+        // LA tiles of loads in flight, no more: sched_barrier keeps hipcc from hoisting all 64 loads (256 registers)
+        // above the arithmetic (that version spilled); statistics in one pass on register quads (packed fp32 math)
+        constexpr int LA = C::NT < 4 ? C::NT : 4;
+        f32x4 xq[LA][4];
+#pragma unroll
+        for (int t = 0; t < LA - 1; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xq[t][g] = *reinterpret_cast<const f32x4*>(xr + 32 * t + 8 * g);
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            if (t + LA - 1 < C::NT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xq[(t + LA - 1) % LA][g] = *reinterpret_cast<const f32x4*>(xr + 32 * (t + LA - 1) + 8 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 q = xq[t % LA][g];
+                s4 += q;
+                q4 += q * q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Y[t][4 * g + e] = PARTIAL ? 0.f : q[e];
+            }
+            acc_pin(Y[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        sum += __shfl_xor(sum, 32);
+        sq += __shfl_xor(sq, 32);
+        const float mean = sum / (float)D;
+        const float var = sq / (float)D - mean * mean;
+        const float rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
+        const float shift = -mean * rstd;
+        __syncthreads();   // (vmcnt(0): the prologue blocks have landed; bias table, vectors and zero block are visible)
+        // k-step ks of fc1 = registers 8 (ks & 1) .. + 7 of tile ks >> 1: element j is column
+        // 16 ks + 8 (j >> 2) + 4 h + (j & 3) -- the permuted k order the W1 image is packed in (mlp_fused_pack, kperm)
+        if constexpr (PARTIAL) {
+#pragma unroll
+            for (int t = 0; t < LA - 1; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xq[t][g] = *reinterpret_cast<const f32x4*>(xr + 32 * t + 8 * g);
+        }
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            f32x16 yt;
+            if constexpr (!PARTIAL) {
+                yt = Y[t];                           // ONE copy of the tile out of the AGPRs (element-wise access re-reads all 16)
+            } else {                                 // hidden-split tiles: the accumulators hold zeros, re-read the row (L1 / L2)
+                if (t + LA - 1 < C::NT) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xq[(t + LA - 1) % LA][g] = *reinterpret_cast<const f32x4*>(xr + 32 * (t + LA - 1) + 8 * g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yt[4 * g + e] = xq[t % LA][g][e];
+            }
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                const int ks = 2 * t + kq;
+                unsigned u[4];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    const int col = 16 * ks + 8 * gq, g = 2 * kq + gq;
+                    const f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(lg_in + col), bv = *reinterpret_cast<const f32x4*>(lb_in + col);
+                    const f32x4 v = (q * rstd + shift) * gv + bv;
+                    u[2 * gq] = pack2(v[0], v[1]);
+                    u[2 * gq + 1] = pack2(v[2], v[3]);
+                }
+                xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     // LDS addressing: one per-lane base (+ a second one 64 KB up: ds offsets are 16 bits), compile-time offsets
     const unsigned lds_lo = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
@@ -206,9 +330,10 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     constexpr int PD = C::F < 8 ? C::F : 8;    // fragment reads in flight ahead of their MFMA: covers ~250 cycles of LDS latency
     const GeluConst gk{3.8f, -4.544908101e-06f};
 
-    // fragment F of the slot's block -> register q; slot and fragment are compile-time, so this is one ds_read_b128
-    auto frag = [&](auto slot_tag, auto f_tag, bf16x8& q) {
-        constexpr int OFF = decltype(slot_tag)::value * C::BLK + decltype(f_tag)::value * 1024;
+    // LDS offset of fragment f of ring slot `slot` relative to lds_lo (compile-time)
+    auto frag_off = [](int slot, int f) constexpr { return slot * C::BLK + f * 1024; };
+    auto frag = [&](auto off_tag, bf16x8& q) {
+        constexpr int OFF = decltype(off_tag)::value;
         if constexpr (OFF < 65536) lds_frag<OFF>(q, lds_lo);
         else lds_frag<OFF - 65536>(q, lds_hi);
     };
@@ -220,98 +345,126 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
         sacc = f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3],
                       q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
     };
-    // the F MFMAs of one phase, fed by a fragment queue PD deep: MFMA f, the read of fragment f + PD, then `gap(f)`
-    auto phase = [&](auto slot_tag, bf16x8 (&wq)[PD], auto&& mma, auto&& gap) {
-        [&]<int... J>(std::integer_sequence<int, J...>) { (frag(slot_tag, std::integral_constant<int, J>{}, wq[J]), ...); }
-        (std::make_integer_sequence<int, PD>{});
-        [&]<int... FI>(std::integer_sequence<int, FI...>) {
-            ([&] {
-                constexpr int f = FI, left = C::F - 1 - f;
-                mma(std::integral_constant<int, f>{}, std::integral_constant<int, (left < PD - 1 ? left : PD - 1)>{}, wq[f % PD]);
-                if constexpr (f + PD < C::F) frag(slot_tag, std::integral_constant<int, f + PD>{}, wq[f % PD]);
-                gap(std::integral_constant<int, f>{});
-            }(), ...);
-        }(std::make_integer_sequence<int, C::F>{});
-    };
 
-    __syncthreads();   // (vmcnt(0): the prologue blocks have landed; bias table and zero block are visible)
-
+    GeluPair gr{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned pw_none = 0;
     f32x16 sA, sB;
     bf16x8 wq[PD];
     bias_init(c0, sA);
-    phase(std::integral_constant<int, 0>{}, wq,
-          [&](auto f, auto lg, const bf16x8& w) { mfma_hid<decltype(lg)::value>(sA, w, xf[decltype(f)::value]); },
-          [&](auto) {});
+    // S of the first chunk from ring slot 0, with a fragment queue of its own
+    [&]<int... J>(std::integer_sequence<int, J...>) { (frag(std::integral_constant<int, frag_off(0, J)>{}, wq[J]), ...); }
+    (std::make_integer_sequence<int, PD>{});
+    [&]<int... FI>(std::integer_sequence<int, FI...>) {
+        ([&] {
+            constexpr int f = FI, left = C::F - 1 - f, LG = left < PD - 1 ? left : PD - 1;
+            constexpr bool RD = f + PD < C::F;
+            constexpr int LO = RD ? frag_off(0, f + PD) : 0;
+            gap_stmt<0, LG, RD, LO, -1>(sA, wq[f % PD], xf[f], lds_lo, 0.f, 0.f, gk, gr, pw_none);
+        }(), ...);
+    }(std::make_integer_sequence<int, C::F>{});
+    // the continuous fragment queue of the loop starts here: first PD fragments of "W2 of chunk c0 - 1" (slot 3: zeros)
+    [&]<int... J>(std::integer_sequence<int, J...>) { (frag(std::integral_constant<int, frag_off(3, J)>{}, wq[J]), ...); }
+    (std::make_integer_sequence<int, PD>{});
 
     // One chunk c, PAR = c & 1.  s_cur = S of chunk c (complete), s_next receives S of chunk c+1, p_prev = GELU of chunk
     // c-1 (zeros for the first chunk), p_out receives the GELU of chunk c.  No branch inside: the last chunk computes a
     // throw-away S from the padded image.
-    //   E: wait W2(c-1) landed | barrier | request W1(c+2) into the slot W1(c) has left
-    //      phase A  Y += W2(c-1) . p_prev                      gaps: GELU pieces 0 .. F*PPG-1 of chunk c
-    //   M: wait W1(c+1) landed | barrier | request W2(c+1) into the slot W2(c-1) has left
-    //      phase B  s_next = b1(c+1) + W1(c+1) . X             gaps: the remaining GELU pieces
-    // DMA groups retire in issue order and at most three are outstanding, so "at most 2 * FPW instructions outstanding"
-    // (counted vmcnt) is "the oldest group has landed"; the raw barrier then extends that to every wave's pieces and
-    // orders the slot hand-over.  Nothing else in the loop touches vmcnt.
+    //
+    // Instruction stream: 2F gaps (gap_stmt) -- F of GEMM2 for chunk c-1 (block W2(c-1)), then F of GEMM1 for chunk c+1
+    // (block W1(c+1)) -- fed by ONE fragment queue PD deep that never drains: it runs on across the phase boundary and
+    // into the next iteration's first block W2(c).  Behind each MFMA: the read PD fragments ahead and one GELU piece of
+    // chunk c.  Two raw barriers per iteration order the ring; neither sits in front of a fragment read:
+    //   E (before gap 0):  wait "W1(c+1) landed" | barrier | then request W1(c+2) into the slot W1(c) has left
+    //   M (before gap F):  wait "W2(c)   landed" | barrier | then request W2(c+1) into the slot W2(c-1) has left
+    // i.e. every block is confirmed half an iteration before its first fragment read and requested a full iteration
+    // before that.  DMA groups (FPW instructions per wave) retire in issue order and at most two are outstanding at a
+    // wait, so vmcnt(FPW) = "the older one has landed"; the barrier extends that to every wave's pieces and orders the
+    // slot hand-over.  Nothing else in the loop touches vmcnt.  The FPW requests of a block are spread over the phase.
     constexpr int PPG = 32 / C::F;             // GELU pieces per gap: 64 pieces (8 pairs x 8) over 2F gaps
+    constexpr int KB = C::F / 2;               // the 4 bias reads of s_next are issued behind gap KB
+    constexpr int DSTEP = C::F / C::FPW;       // one LDS-DMA request every DSTEP gaps (4)
     auto iteration = [&](auto par_tag, int c, f32x16& s_cur, f32x16& s_next, const bf16x8 (&p_prev)[2], bf16x8 (&p_out)[2]) {
         constexpr int PAR = decltype(par_tag)::value;
-        using SlotW2P [[maybe_unused]] = std::integral_constant<int, PAR ? 1 : 3>;      // W2 of chunk c-1: block 2c-1
-        using SlotW1N [[maybe_unused]] = std::integral_constant<int, PAR ? 0 : 2>;      // W1 of chunk c+1: block 2c+2
-        GeluPair gr;
+        constexpr int SLOT_A = PAR ? 1 : 3;        // W2 of chunk c-1: block 2c-1
+        constexpr int SLOT_B = PAR ? 0 : 2;        // W1 of chunk c+1: block 2c+2
+        constexpr int SLOT_N = PAR ? 3 : 1;        // W2 of chunk c: block 2c+1, the next iteration's first block
+        constexpr int NG = 2 * C::F;
         unsigned pw[8];
-        [[maybe_unused]] auto gap = [&](auto g_tag) {           // gap g of the iteration (0 .. 2F-1): PPG pieces
-            [&]<int... Q>(std::integer_sequence<int, Q...>) {
-                ([&] {
-                    constexpr int id = decltype(g_tag)::value * PPG + Q, pair = id >> 3;
-                    gelu_piece<(id & 7)>(s_cur[2 * pair], s_cur[2 * pair + 1], gk, gr, pw[pair]);
-                }(), ...);
-            }(std::make_integer_sequence<int, PPG>{});
-        };
-        wait_vmcnt<2 * C::FPW>();
-        __builtin_amdgcn_s_barrier();
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1     // development builds only (tools/build_variant.py): 1 = no DMA in the loop
-        dma_block(2 * c + 4, PAR ? 2 : 0);
+        const char* src_e = a.wimg + (size_t)(2 * c + 4) * C::BLK + (wave * C::FPW) * 1024 + lane * 16;   // W1(c+2) -> slot of W1(c)
+        const char* src_m = a.wimg + (size_t)(2 * c + 3) * C::BLK + (wave * C::FPW) * 1024 + lane * 16;   // W2(c+1) -> slot of W2(c-1)
+        char* dst_e = smem + (PAR ? 2 : 0) * C::BLK + (wave * C::FPW) * 1024;
+        char* dst_m = smem + (PAR ? 1 : 3) * C::BLK + (wave * C::FPW) * 1024;
+        [&]<int... GI>(std::integer_sequence<int, GI...>) {
+            ([&] {
+                constexpr int g = GI;
+                if constexpr (g == 0 || g == C::F) {
+                    wait_vmcnt<C::FPW>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                // fragment read PD gaps ahead: this iteration's slots, or the next iteration's first block
+                constexpr int gn = g + PD;
+                constexpr int LO = gn < C::F ? frag_off(SLOT_A, gn) : gn < NG ? frag_off(SLOT_B, gn - C::F) : frag_off(SLOT_N, gn - NG);
+                constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+                const unsigned la = LO < 65536 ? lds_lo : lds_hi;
+                // the bias reads issued behind gap KB are younger than the fragments of gaps KB+1 .. KB+PD
+                constexpr int LG = PD - 1 + ((g > KB && g <= KB + PD) ? 4 : 0);
+#if defined(DD_MLP_ABLATE) && DD_MLP_ABLATE == 3      // development builds only (tools/build_variant.py): 3 = no GELU
+                constexpr int K = -1;
+                pw[(g * PPG) >> 3] = 0x3c003c00u;
+#else
+                constexpr int id0 = g * PPG;
+                constexpr int K = PPG == 1 ? (id0 & 7) : -1;
 #endif
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 2     // 2 = DMA stream + barriers only
-        phase(SlotW2P{}, wq,
-              [&](auto f, auto lg, const bf16x8& w) {
-                  constexpr int fi = decltype(f)::value;
-                  mfma_acc<decltype(lg)::value, false>(Y[fi >> 1], w, p_prev[fi & 1]);
-              },
-              [&](auto f) { gap(f); });
+                constexpr int pair = (g * PPG) >> 3;
+                if constexpr (g < C::F)
+                    gap_stmt<1, LG, true, LOA, K>(Y[g >> 1], wq[g % PD], p_prev[g & 1], la, s_cur[2 * pair], s_cur[2 * pair + 1], gk, gr, pw[pair]);
+                else
+                    gap_stmt<0, LG, true, LOA, K>(s_next, wq[g % PD], xf[g - C::F], la, s_cur[2 * pair], s_cur[2 * pair + 1], gk, gr, pw[pair]);
+#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 3
+                if constexpr (PPG > 1) {   // D < 512: several GELU pieces per gap, as statements of their own
+                    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                        ([&] {
+                            constexpr int id = g * PPG + Q, pr = id >> 3;
+                            gelu_piece<(id & 7)>(s_cur[2 * pr], s_cur[2 * pr + 1], gk, gr, pw[pr]);
+                        }(), ...);
+                    }(std::make_integer_sequence<int, PPG>{});
+                }
 #endif
-        wait_vmcnt<2 * C::FPW>();
-        __builtin_amdgcn_s_barrier();
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1
-        dma_block(2 * c + 3, PAR ? 1 : 3);
+                if constexpr (g == KB) bias_init(c + 1, s_next);
+#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1     // 1 = no DMA in the loop
+                if constexpr (g % DSTEP == DSTEP / 2) {
+                    constexpr int j = (g % C::F) / DSTEP;
+                    if constexpr (g < C::F) glds16(src_e + j * 1024, dst_e + j * 1024);
+                    else glds16(src_m + j * 1024, dst_m + j * 1024);
+                }
 #endif
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 2
-        bias_init(c + 1, s_next);
-        phase(SlotW1N{}, wq,
-              [&](auto f, auto lg, const bf16x8& w) { mfma_hid<decltype(lg)::value>(s_next, w, xf[decltype(f)::value]); },
-              [&](auto f) { gap(std::integral_constant<int, C::F + decltype(f)::value>{}); });
+            }(), ...);
+        }(std::make_integer_sequence<int, NG>{});
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         p_out[0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
         p_out[1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
-#endif
     };
 
     bf16x8 pA[2], pB[2];
     pA[0] = pA[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(DD_MLP_ABLATE) && DD_MLP_ABLATE == 5      // development builds only: 5 = prologue + tail + epilogue, no chunk loop
+    c1 = c0;
+#endif
     for (int c = c0; c < c1; c += 2) {   // c0 and c1 are even (mlp_fused_plan): no control flow around the accumulators
         iteration(std::integral_constant<int, 0>{}, c, sA, sB, pA, pB);
         iteration(std::integral_constant<int, 1>{}, c + 1, sB, sA, pB, pA);
     }
-    // tail: GEMM2 of the last chunk (c1 - 1 is odd: its W2 block sits in slot 3)
-    wait_vmcnt<2 * C::FPW>();
-    __builtin_amdgcn_s_barrier();
-    phase(std::integral_constant<int, 3>{}, wq,
-          [&](auto f, auto lg, const bf16x8& w) {
-              constexpr int fi = decltype(f)::value;
-              mfma_acc<decltype(lg)::value, (fi < 2)>(Y[fi >> 1], w, pA[fi & 1]);
-          },
-          [&](auto) {});
+    // tail: GEMM2 of the last chunk; its block W2(c1-1) (slot 3) was confirmed at the last M barrier and the first PD
+    // fragments are already in flight
+    [&]<int... FI>(std::integer_sequence<int, FI...>) {
+        ([&] {
+            constexpr int f = FI, left = C::F - 1 - f, LG = left < PD - 1 ? left : PD - 1;
+            constexpr bool RD = f + PD < C::F;
+            constexpr int LO = RD ? frag_off(3, f + PD) : 0;
+            constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+            gap_stmt<1, LG, RD, LOA, -1>(Y[f >> 1], wq[f % PD], pA[f & 1], LO < 65536 ? lds_lo : lds_hi, 0.f, 0.f, gk, gr, pw_none);
+        }(), ...);
+    }(std::make_integer_sequence<int, C::F>{});
     wait_vmcnt<0>();     // the run-ahead DMA of the padded blocks must not outlive the workgroup's LDS allocation
     // hipcc does not know that the asm statements are MFMAs: left alone it schedules its own reads of the accumulators
     // (v_accvgpr_read, AGPR spills) directly behind the last MFMA, inside its 12-wait-state shadow.  The drain, then one
@@ -321,76 +474,171 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     for (int t = 0; t < C::NT; ++t) asm volatile("" : "+a"(Y[t]));
 
     // ---- epilogue.  Accumulator layout: lane = token row, register quad g of tile t = columns 32t + 8g + 4h .. +3.
-    if (partial) {
-        float* pp = a.partial + ((long long)slab * 128 + wave * 32 + r32) * D + 4 * h;
+    const int he = half_of();
+    if constexpr (PARTIAL) {
+        float* pp = a.partial + ((long long)slab * 128 + wave * 32 + r32) * D + 4 * he;
 #pragma unroll
-        for (int t = 0; t < C::NT; ++t)
+        for (int t = 0; t < C::NT; ++t) {
+            const f32x16 yt = Y[t];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(pp + 32 * t + 8 * g) = f32x4{Y[t][4 * g], Y[t][4 * g + 1], Y[t][4 * g + 2], Y[t][4 * g + 3]};
-        return;
-    }
-    float* xrow = a.xres + row * D + 4 * h;
-    const float* b2 = a.b2 + 4 * h;
-    f32x4 xl[2][4];   // residual quads of tile t, loaded one tile ahead of the stores (vmcnt retires in order)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) xl[0][g] = *reinterpret_cast<const f32x4*>(xrow + 8 * g);
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t) {
-        if (t + 1 < C::NT) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xl[(t + 1) & 1][g] = *reinterpret_cast<const f32x4*>(xrow + 32 * (t + 1) + 8 * g);
+                *reinterpret_cast<f32x4*>(pp + 32 * t + 8 * g) = f32x4{yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
         }
-        uint2 v[4];
+    } else {
+        bool row_ok;
+        const long long row = row_of(row_ok);
+        if (!row_ok) return;     // rows past the end of a ragged last tile (both lanes of a row agree; no barrier follows)
+        const float* lg_out = vecs + 2 * D + 4 * he;
+        const float* lb_out = vecs + 3 * D + 4 * he;
+        const float* lb2 = vecs + 4 * D + 4 * he;
+        float* xrow = a.xres + row * D + 4 * he;
+        f32x4 xl[2][4];   // !LNIN: residual quads of tile t, loaded one tile ahead of the stores (vmcnt retires in order)
+        if constexpr (!LNIN) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 q = {Y[t][4 * g], Y[t][4 * g + 1], Y[t][4 * g + 2], Y[t][4 * g + 3]};
-            q += *reinterpret_cast<const f32x4*>(b2 + 32 * t + 8 * g);
-            q = xl[t & 1][g] + q;
-            if (row_ok) *reinterpret_cast<f32x4*>(xrow + 32 * t + 8 * g) = q;
-            v[g] = uint2{pack2(q[0], q[1]), pack2(q[2], q[3])};
+            for (int g = 0; g < 4; ++g) xl[0][g] = *reinterpret_cast<const f32x4*>(xrow + 8 * g);
         }
-        if (a.out) {
-            // bf16 copy as 16-byte row segments: v_permlane32_swap joins the two lane halves (see gemm.hip)
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int gp = 0; gp < 4; gp += 2) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
-                const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                if (row_ok) *reinterpret_cast<uint4*>(a.out + row * a.ldo + 32 * t + 8 * gp + 8 * h) = o;
+        for (int t = 0; t < C::NT; ++t) {
+            if constexpr (!LNIN) {
+                if (t + 1 < C::NT) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xl[(t + 1) & 1][g] = *reinterpret_cast<const f32x4*>(xrow + 32 * (t + 1) + 8 * g);
+                }
+            }
+            uint2 v[4];
+            const f32x16 yt = Y[t];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
+                q += *reinterpret_cast<const f32x4*>(lb2 + 32 * t + 8 * g);
+                if constexpr (!LNIN) q = xl[t & 1][g] + q;
+                *reinterpret_cast<f32x4*>(xrow + 32 * t + 8 * g) = q;
+                v[g] = uint2{pack2(q[0], q[1]), pack2(q[2], q[3])};
+                s4 += q;
+                q4 += q * q;
+            }
+            if (a.out) {
+                // bf16 copy as 16-byte row segments: v_permlane32_swap joins the two lane halves (see gemm.hip)
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
+                    const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<uint4*>(a.out + row * a.ldo + 32 * t + 8 * gp + 8 * he) = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // tile by tile: keeps the live set small (no spills)
+        }
+        if (LNIN && a.ln_out) {   // LayerNorm of the updated row (the next block's norm1) as bf16, from the registers (LNIN mode only)
+            float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            sum += __shfl_xor(sum, 32);
+            sq += __shfl_xor(sq, 32);
+            const float mean = sum / (float)D;
+            const float var = sq / (float)D - mean * mean;
+            const float rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
+            const float shift = -mean * rstd;
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                uint2 v[4];
+                const f32x16 yt = Y[t];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // the updated row is rebuilt from the (read-only) accumulators: cheaper than writing it back in pass 1
+                    f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
+                    q += *reinterpret_cast<const f32x4*>(lb2 + 32 * t + 8 * g);
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(lg_out + 32 * t + 8 * g), bv = *reinterpret_cast<const f32x4*>(lb_out + 32 * t + 8 * g);
+                    const f32x4 w = (q * rstd + shift) * gv + bv;
+                    v[g] = uint2{pack2(w[0], w[1]), pack2(w[2], w[3])};
+                }
+#pragma unroll
+                for (int gp2 = 0; gp2 < 4; gp2 += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp2].x, v[gp2 + 1].x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp2].y, v[gp2 + 1].y, false, false);
+                    const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<uint4*>(a.ln_out + row * D + 32 * t + 8 * gp2 + 8 * he) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 }
 
-// x[row] += b2 + sum over the groups' partial slabs (fixed order), for the rows of the leftover tiles
-__global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a, int D) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one float4 each
-    const int qpr = D / 4;
-    if (i >= (long long)a.n_extra * qpr) return;
-    const long long r = i / qpr;                                       // logical extra row
-    const int col = (int)(i - r * qpr) * 4;
+// LNIN = false: the input rows are a.X (bf16, e.g. the output of a LayerNorm kernel) and the residual x is read in the
+//               epilogue;
+// LNIN = true:  the kernel reads the fp32 residual rows x ONCE, straight into the output accumulators (x is then already
+//               part of Y: no second read), computes LayerNorm(x) * gamma + beta in registers (reference
+//               models/uvit.py:207 norm2) and converts the normalised accumulator registers in place into the MFMA
+//               B fragments of fc1 -- their k order is the accumulator order, the W1 image is packed to match.
+// Either way an optional second LayerNorm (the NEXT block's norm1, models/uvit.py:206) of the updated rows is written
+// as bf16 from the epilogue (a.ln_out), so neither LayerNorm of a block needs a launch or an HBM round trip of x.
+// Workgroups [0, tiles_main) take a main tile each; the rest are the hidden-split workgroups of the extra-token tiles.
+template <int D, bool LNIN>
+__global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < a.tiles_main) {
+        mlp_body<D, LNIN, false>(a, smem, blockIdx.x, 0, a.nchunks, 0);
+    } else {
+        const int e = blockIdx.x - a.tiles_main;
+        const int lt = e / a.groups, g = e - lt * a.groups;
+        const int c0 = g * a.cpg;
+        mlp_body<D, LNIN, true>(a, smem, lt, c0, c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks, e);
+    }
+}
+
+// Extra-token rows: x[row] += b2 + sum over the groups' partial slabs (fixed order), the optional bf16 copy, and the
+// optional LayerNorm of the updated row (the next block's norm1).  One wave per row, VPL = D / 64 columns per lane.
+template <int VPL>
+__global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
+    constexpr int D = VPL * 64;
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // logical extra row
+    if (r >= a.n_extra) return;
     const int lt = (int)(r / 128), rr = (int)(r % 128);
     const long long b = r / a.tok_e;
     const long long row = b * a.tok_l + (r - b * a.tok_e);
-    f32x4 acc = *reinterpret_cast<const f32x4*>(a.b2 + col);
-    for (int g = 0; g < a.groups; ++g)
-        acc += *reinterpret_cast<const f32x4*>(a.partial + (((long long)lt * a.groups + g) * 128 + rr) * D + col);
-    f32x4* xp = reinterpret_cast<f32x4*>(a.xres + row * D + col);
-    const f32x4 q = *xp + acc;
-    *xp = q;
-    if (a.out) *reinterpret_cast<uint2*>(a.out + row * a.ldo + col) = uint2{pack2(q[0], q[1]), pack2(q[2], q[3])};
+    const int col = lane * VPL;
+    float acc[VPL], xv[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) acc[e] = a.b2[col + e];
+    for (int g = 0; g < a.groups; ++g) {
+        const float* pp = a.partial + (((long long)lt * a.groups + g) * 128 + rr) * D + col;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) acc[e] += pp[e];
+    }
+    float* xp = a.xres + row * D + col;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) { xv[e] = xp[e] + acc[e]; xp[e] = xv[e]; sum += xv[e]; }
+    if (a.out) {
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) a.out[row * a.ldo + col + e] = f2bf(xv[e]);
+    }
+    if (a.ln_out) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)D;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) { const float d = xv[e] - mean; q2 += d * d; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) q2 += __shfl_xor(q2, o);
+        const float rstd = 1.0f / sqrtf(q2 / (float)D + 1e-5f);
+#pragma unroll
+        for (int e = 0; e < VPL; ++e)
+            a.ln_out[row * D + col + e] = f2bf((xv[e] - mean) * rstd * a.ln_out_g[col + e] + a.ln_out_b[col + e]);
+    }
 }
 
 template <int D>
 hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
-    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float);   // + one chunk: bias_init(c1) is read, unused
+    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 5 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 5 column vectors
     const int grid = a.tiles_main + a.tiles_left * a.groups;
-    hipLaunchKernelGGL(mlp_fused_kernel<D>, dim3(grid), dim3(256), lds, s, a);
+    if (a.ln_in_g) hipLaunchKernelGGL((mlp_fused_kernel<D, true>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mlp_fused_kernel<D, false>), dim3(grid), dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.tiles_left > 0) {
-        const long long n4 = (long long)a.n_extra * (D / 4);
-        hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, D);
+        hipLaunchKernelGGL(mlp_reduce_kernel<D / 64>, dim3((unsigned)((a.n_extra + 3) / 4)), dim3(256), 0, s, a);
         e = hipGetLastError();
     }
     return e;
@@ -430,7 +678,9 @@ size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden) {
 }
 
 // Host: nn.Linear weights (fp32, [out, in]) -> the fragment-ordered bf16 image the kernel streams + permuted fc1 bias.
-void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2,
+// kperm: W1's k index inside every group of 16 is permuted to the accumulator order (the kernel's LNIN mode builds the
+// fc1 B fragments from accumulator registers); W2's k index always is.
+void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
                     unsigned short (*to_bf16)(float), unsigned short* img, float* b1p) {
     const int F = D / 16, NT = D / 32, KS = D / 16, nchunks = hidden / 32;
     for (int c = 0; c < nchunks; ++c) {
@@ -439,8 +689,10 @@ void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const f
         for (int lane = 0; lane < 64; ++lane) {
             const int r = lane & 31, h = lane >> 5;
             for (int ks = 0; ks < KS; ++ks)
-                for (int j = 0; j < 8; ++j)
-                    blk1[(size_t)ks * 512 + lane * 8 + j] = to_bf16(w1[(size_t)(32 * c + r) * D + 16 * ks + 8 * h + j]);
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * ks + (kperm ? 8 * (j >> 2) + 4 * h + (j & 3) : 8 * h + j);
+                    blk1[(size_t)ks * 512 + lane * 8 + j] = to_bf16(w1[(size_t)(32 * c + r) * D + k]);
+                }
             for (int t = 0; t < NT; ++t)
                 for (int s = 0; s < 2; ++s)
                     for (int j = 0; j < 8; ++j) {
@@ -455,10 +707,13 @@ void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const f
 
 hipError_t init_mlp_fused_kernels() {
     hipError_t e = hipSuccess;
-    const int bias = (kMaxHidden + 32) * (int)sizeof(float);
+    const int bias = (kMaxHidden + 32 + 5 * 512) * (int)sizeof(float);
 #define DD_ATTR(DV)                                                                                          \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                MlpCfg<DV>::RING + bias);                                                    \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 MlpCfg<DV>::RING + bias);
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR

@@ -19,25 +19,33 @@ def main():
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", f"-I{REPO / 'include'}",
                     "-S", "--cuda-device-only", str(SRC), "-o", out], check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l))
-    end = next(j for j in range(start, len(lines)) if "s_endpgm" in lines[j])
-    body = lines[start:end]
-    loop = []
-    for head in (i for i, l in enumerate(body) if "Loop Header" in l):       # the hot loop = the longest loop body
-        label = body[head].split(":")[0]
-        back = next(i for i in range(head, len(body)) if re.search(r"s_cbranch_\w+\s+" + re.escape(label) + r"\b", body[i]))
-        if back - head + 1 > len(loop):
-            loop = body[head:back + 1]
-    cnt = lambda pat: sum(bool(re.search(pat, l)) for l in loop)
-    rep = {"lines": len(loop), "mfma": cnt(r"v_mfma"), "ds_read_b128": cnt(r"ds_read_b128"), "lds_dma": cnt(r"global_load_lds"),
-           "barrier": cnt(r"s_barrier"), "scratch": cnt(r"scratch_"), "accvgpr": cnt(r"v_accvgpr"), "v_mov": cnt(r"\bv_mov"),
-           "ds_write": cnt(r"ds_write"), "waitcnt_vm0": cnt(r"s_waitcnt vmcnt\(0\)")}
-    total_scratch = sum("scratch_" in l for l in body)
-    print(rep, "| scratch ops in whole kernel:", total_scratch)
-    ok = (rep["scratch"] == 0 and rep["accvgpr"] == 0 and rep["v_mov"] == 0 and rep["ds_write"] == 0 and rep["waitcnt_vm0"] == 0
-          and rep["mfma"] == 128 and rep["ds_read_b128"] == 128 + 8 and rep["lds_dma"] == 32 and rep["barrier"] == 4)
-    print("AUDIT", "OK" if ok else "FAILED")
-    return 0 if ok else 1
+    rc = 0
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
+    assert len(starts) == 2, "expected the LNIN = false / true instantiations"
+    for start in starts:
+        end = next(j for j in range(start, len(lines)) if "s_endpgm" in lines[j])
+        body = lines[start:end]
+        loops = []
+        for head in (i for i, l in enumerate(body) if "Loop Header" in l):
+            label = body[head].split(":")[0]
+            back = next((i for i in range(head, len(body)) if re.search(r"s_cbranch_\w+\s+" + re.escape(label) + r"\b", body[i])), None)
+            if back is not None and sum("v_mfma" in l for l in body[head:back + 1]) >= 64:
+                loops.append(body[head:back + 1])          # the chunk loops of the main and of the hidden-split body
+        ok = len(loops) == 2
+        for loop in loops:
+            cnt = lambda pat: sum(bool(re.search(pat, l)) for l in loop)
+            rep = {"lines": len(loop), "mfma": cnt(r"v_mfma"), "ds_read_b128": cnt(r"ds_read_b128"), "lds_dma": cnt(r"global_load_lds"),
+                   "barrier": cnt(r"s_barrier"), "scratch": cnt(r"scratch_"), "accvgpr": cnt(r"v_accvgpr"), "v_mov": cnt(r"\bv_mov"),
+                   "ds_write": cnt(r"ds_write"), "waitcnt_vm0": cnt(r"s_waitcnt vmcnt\(0\)"), "s_nop": cnt(r"s_nop")}
+            good = (rep["scratch"] == 0 and rep["accvgpr"] == 0 and rep["v_mov"] == 0 and rep["ds_write"] == 0 and rep["waitcnt_vm0"] == 0
+                    and rep["mfma"] == 128 and rep["ds_read_b128"] == 128 + 8 and rep["lds_dma"] == 32 and rep["barrier"] == 4)
+            print("  loop:", rep, "OK" if good else "FAILED")
+            ok = ok and good
+        total_scratch = sum("scratch_" in l for l in body)
+        print(lines[start].split(":")[0][-40:], "| instructions:", sum(l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;") for l in body),
+              "| scratch ops in whole kernel:", total_scratch, "| AUDIT", "OK" if ok else "FAILED")
+        rc |= 0 if ok else 1
+    return rc
 
 
 if __name__ == "__main__":
