@@ -100,12 +100,20 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("DUODIFF_DIST_BACKEND", "nccl")     # gloo: rehearsal / CPU test of the launch plumbing
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        log(f"process group initialised: rank {rank} of world {world}, backend {backend}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path (duodiff_amd._lib.EngineUnavailable)")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
     from duodiff_amd import sampler
     from duodiff_amd.engine import sample_loop
@@ -149,7 +157,12 @@ def main():
         ctx.to_images(x, out=imgs, stream=stream)
         if dist is not None:
             with torch.cuda.stream(stream):
-                dist.all_gather(gathered, imgs)                  # the single collective: final images
+                if dist.get_backend() == "nccl":
+                    dist.all_gather(gathered, imgs)              # the single collective: final images (RCCL over xGMI)
+                else:                                            # gloo rehearsal: host memory
+                    stream.synchronize()
+                    host = [torch.empty(imgs.shape) for _ in range(world)]
+                    dist.all_gather(host, imgs.cpu())
 
     # warm-up: W untimed steps touching both backbones (captures the graphs) followed by the EXACT tail of the timed
     # pass (output kernel, all_gather), so that no first-use cost (code-object load, graph upload, communicator
@@ -174,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing = ctx.last_sample_timing()   # hipEvents around the K steps of this rank's dd_sample call
-    t_all = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t_all = torch.tensor([dt], device=dev if dist is None or dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt = float(t_all.item())
@@ -186,24 +199,29 @@ def main():
         value = images / (dt * 1000.0 / K)
         flop_img = 0.3 * mp_s.flops_per_image() * 1000 + 0.7 * mp_f.flops_per_image() * 1000
         e2e_tflops = value * flop_img / 1e12 / world
-        # dominant kernel: fc1 GEMM + bias + GELU of the full model (2/3 of the block's Linear FLOPs
-        # are the MLP pair), timed live with hipEvents on the launch stream
-        # measured IN CONTEXT: hipEvent pairs on the launch stream around every fc1 launch of 20 eager
-        # full-model steps run right after the timed region (same buffers, cache and clock state as the run)
+        # Dominant kernel: the fused MLP launch of the full model's blocks (mlp_fused_kernel: norm2 + fc1 + bias + exact-erf
+        # GELU + fc2 + bias + residual + next norm1, plus its small extra-token reduce launch) -- 2/3 of a block's Linear
+        # FLOPs.  Timed live IN CONTEXT: hipEvent pairs on the launch stream around every such launch of 20 eager
+        # full-model steps run right after the timed region (same buffers, cache and clock state as the run).
         with torch.cuda.stream(stream):
             ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, stream=stream)
-        fl = 2.0 * B * mp_f.seq_len * 4 * mp_f.embed_dim * mp_f.embed_dim
+        M_rows, D_, H_ = B * mp_f.seq_len, mp_f.embed_dim, 4 * mp_f.embed_dim
+        fl = 2.0 * M_rows * D_ * H_ * 2                  # fc1 + fc2
         ach = fl / (ms * 1e-3) / 1e12
-        # HBM bytes of that kernel per launch from the committed two-pass PMC profile (FETCH_SIZE x2 gfx950
-        # correction + WRITE_SIZE; tools/pmc_summary.py) -- rocprofv3 cannot run inside this process
+        # algorithmic bytes of one launch: fp32 residual rows read once and written once, bf16 copy for the long skip,
+        # bf16 norm1 output for the next block, the bf16 weights once
+        alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2) + 2 * D_ * H_ * 2
+        # HBM bytes / MFMA-busy fraction of that kernel come from the COMMITTED rocprofv3 --pmc profile of this build
+        # (profiles/r02/pmc_traffic.json, pmc_sq.json; FETCH_SIZE corrected per profiles/r02/fetch_calibration.txt): they are
+        # profile references, not measured in this run -- rocprofv3 cannot run inside this process
         traffic = None
         mfma_busy = None
         try:
-            pmc = json.load(open(REPO / "profiles" / "r01_pmc_traffic.json"))
-            k = next(v for n, v in pmc.items() if "gemm256_kernel<1>" in n or "gemm256_kernel<1, 0>" in n)
+            pmc = json.load(open(REPO / "profiles" / "r02" / "pmc_traffic.json"))
+            k = next(v for n, v in pmc.items() if "mlp_fused_kernel" in n)
             traffic = (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6
-            sq = json.load(open(REPO / "profiles" / "r01_pmc_sq.json"))
-            mfma_busy = next(v["mfma_busy_frac"] for n, v in sq.items() if "gemm256_kernel<1" in n)
+            sq = json.load(open(REPO / "profiles" / "r02" / "pmc_sq.json"))
+            mfma_busy = next(v["mfma_busy_frac"] for n, v in sq.items() if "mlp_fused_kernel" in n)
         except Exception:
             pass
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
@@ -220,16 +238,19 @@ def main():
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],
                        "host_overhead_ms": dt * 1000.0 - timing[0]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
-                         "algorithmic_bytes": (B * mp_f.seq_len * mp_f.embed_dim + 4 * mp_f.embed_dim * mp_f.embed_dim + B * mp_f.seq_len * 4 * mp_f.embed_dim) * 2,
-                         "kernel": "gemm256_kernel<EPI_BIAS_GELU> (fc1: bias + exact-erf GELU fused) M=%d N=%d K=%d" % (B * mp_f.seq_len, 4 * mp_f.embed_dim, mp_f.embed_dim),
-                         "ms_per_launch": ms, "launches_timed": n_launch, "flops_per_launch": fl,
+                         "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "bytes/launch from the committed rocprofv3 --pmc profile profiles/r02/pmc_traffic.json (not measured in this run)",
+                         "algorithmic_bytes": alg_bytes,
+                         "kernel": "mlp_fused_kernel<512> + mlp_reduce_kernel (norm2 + fc1 + GELU + fc2 + residual + next norm1) M=%d D=%d hidden=%d" % (M_rows, D_, H_),
+                         "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
+                         "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
                          "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": 8000.0,
                          "mfma_busy_frac_pmc": mfma_busy,
+                         "mfma_busy_source": "committed profile profiles/r02/pmc_sq.json (not measured in this run)",
                          "sustained_mfma_tflops_random_operands": 1910.0,
-                         "sustained_note": "register-only v_mfma_f32_32x32x16_bf16 loop, random operands, measured on MI355X "
-                                           "(tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
+                         "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
+                                           "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
         }
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline ...")

@@ -12,7 +12,7 @@ DD_PREC_BF16, DD_PREC_FP32 = 0, 1
 DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
 DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
 DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class dd_config(C.Structure):
@@ -28,7 +28,7 @@ class dd_sample_args(C.Structure):
                 ("y_dev", C.c_void_p), ("x_dev", C.c_void_p), ("B", C.c_int32), ("reserved", C.c_int32)]
 
 
-# every symbol include/duodiff.h declares: name -> (restype, argtypes)
+# every symbol include/duodiff.h (and include/duodiff_dev.h: dd_dev_*) declares: name -> (restype, argtypes)
 SIGNATURES = {
     "dd_abi_version": (C.c_int, []),
     "dd_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -65,10 +65,7 @@ SIGNATURES = {
     "dd_vae_destroy": (None, [C.c_void_p]),
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
-    "dd_dev_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                              C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
-    "dd_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_plan_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dd_last_sample_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -5,6 +5,7 @@
 // get_samples DDPM branch and backbone switch (sampler.py:128-139), schedule constants
 // (sampler.py:40-44, ddpm_core.py:64-70).
 #include "../../include/duodiff.h"
+#include "../../include/duodiff_dev.h"
 #include "dd_internal.h"
 
 #include <cmath>
@@ -22,7 +23,7 @@ namespace dd {
 hipError_t init_gemm_kernels();
 hipError_t init_attention_kernels();
 hipError_t init_rowops_kernels();
-int gemm_num_cus();
+int device_num_cus();
 }  // namespace dd
 
 // ------------------------------------------------------------------------------------------
@@ -34,6 +35,7 @@ struct dd_ctx {
     StepCoef coef_host[1000];
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float timing[3] = {0, 0, 0};
+    int num_cus = 256;           // CU count the persistent GEMM grids are sized for (dd_set_num_cus), a multiple of 8
 };
 
 namespace {
@@ -100,6 +102,7 @@ int ctx_fail(dd_ctx* c, int code, const std::string& msg) {
     return code;
 }
 int ctx_device(dd_ctx* c) { return c->device; }
+int ctx_num_cus(dd_ctx* c) { return c->num_cus; }
 }  // namespace dd
 
 namespace {
@@ -339,7 +342,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
             DD_HIP(c, launch_layernorm<float>(m->x, hd.ng, hd.nb, hf, M, D, s));
             GemmArgs<float> g{hf, nullptr, hd.wdec, hd.bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
-            DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s));
+            DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s, c->num_cus));
             const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
             FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
                          c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
@@ -351,18 +354,18 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             const int oi = bi - m->half_depth - 1;
             const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s));
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
         }
         if (!h_ready) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
         h_ready = false;
         {
             GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, nullptr, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_STORE, s));
+            DD_HIP(c, launch_gemm<T>(g, EPI_STORE, s, c->num_cus));
         }
         DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
         {
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
         if (!(sizeof(T) == 2 && m->fused_mlp)) DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));   // fused MLP: norm2 in its prologue
         // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
@@ -399,13 +402,13 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hid_ld};
             const bool timed = !m->fused_mlp;
             if (timed) if (int rc = mark()) return rc;
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s));
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s, c->num_cus));
             if (timed) if (int rc = mark()) return rc;
         }
         {
             GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
                           m->hid_ld, m->hid_ld, D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s));
+            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
     }
     // output head (uvit.py:377-378): final LayerNorm in fp32 into scratch (the MLP hidden buffer is
@@ -414,7 +417,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     float* hf = (float*)m->hid;
     DD_HIP(c, launch_layernorm<float>(m->x, m->norm_g, m->norm_b, hf, M, D, s));
     GemmArgs<float> g{hf, nullptr, m->wdec, m->bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
-    DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s));
+    DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s, c->num_cus));
     return DD_OK;
 }
 
@@ -502,6 +505,7 @@ int dd_ctx_create(int device, dd_ctx** out) {
     dd_ctx* c = new (std::nothrow) dd_ctx();
     if (!c) return DD_ERR_NOMEM;
     c->device = device;
+    c->num_cus = device_num_cus();
     const Schedule& s = schedule();
     for (int i = 0; i < 1000; ++i) c->coef_host[i] = StepCoef{s.c1[i], s.c2[i], s.sigma[i], s.sigma_beta[i]};
     bool ok = hipMalloc(&c->st, sizeof(StepState)) == hipSuccess && hipMalloc(&c->coef, sizeof(StepCoef) * 1000) == hipSuccess &&
@@ -954,11 +958,11 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
         if (m->prec == DD_PREC_BF16) {
             GemmArgs<bf16_t> g{(const bf16_t*)m->h, nullptr, (const bf16_t*)w.fc1_w, w.fc1_b, nullptr, (bf16_t*)m->hid,
                                M, m->hidden, D, D, D, 0, m->hid_ld};
-            return launch_gemm<bf16_t>(g, EPI_BIAS_GELU, s);
+            return launch_gemm<bf16_t>(g, EPI_BIAS_GELU, s, c->num_cus);
         }
         GemmArgs<float> g{(const float*)m->h, nullptr, (const float*)w.fc1_w, w.fc1_b, nullptr, (float*)m->hid,
                           M, m->hidden, D, D, D, 0, m->hid_ld};
-        return launch_gemm<float>(g, EPI_BIAS_GELU, s);
+        return launch_gemm<float>(g, EPI_BIAS_GELU, s, c->num_cus);
     };
     DD_HIP(c, once());
     hipEvent_t e0, e1;
@@ -1039,13 +1043,6 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     return DD_OK;
 }
 
-int dd_set_gemm_variant(dd_ctx* c, int variant) {
-    if (!c) return DD_ERR_INVALID;
-    if (variant < 0 || (variant > 8 && variant != 14)) return fail(c, DD_ERR_INVALID, "unknown GEMM variant");
-    set_gemm_variant(variant);
-    return DD_OK;
-}
-
 int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out) {
     if (!q_out || !e_out) return DD_ERR_INVALID;
     return plan_rows_256(M, N, K, num_cus, q_out, e_out) ? DD_OK : DD_ERR_UNSUPPORTED;
@@ -1054,95 +1051,7 @@ int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out) {
 int dd_set_num_cus(dd_ctx* c, int n) {
     if (!c) return DD_ERR_INVALID;
     if (n < 8) return fail(c, DD_ERR_INVALID, "need at least 8 CUs");
-    set_gemm_num_cus(n);
-    return DD_OK;
-}
-
-int dd_dev_gemm(dd_ctx* c, int M, int N, int K, int variant, int epilogue, int iters, int check, void* stream,
-                float* ms_out, long long* mismatch_out) {
-    if (!c || !ms_out || M < 1 || N < 1 || K < 64 || K % 64 || iters < 1) return DD_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t Mp = (size_t)round_up(M, 256);
-    bf16_t *A = nullptr, *W = nullptr, *out0 = nullptr, *out1 = nullptr;
-    float *bias = nullptr, *x0 = nullptr, *x1 = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)A, (void*)W, (void*)out0, (void*)out1, (void*)bias, (void*)x0, (void*)x1})
-            if (p) (void)hipFree(p);
-    };
-#define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
-    DD_TRY(hipMalloc((void**)&A, Mp * K * 2));
-    DD_TRY(hipMalloc((void**)&W, (size_t)N * K * 2));
-    DD_TRY(hipMalloc((void**)&out0, Mp * N * 2));
-    DD_TRY(hipMalloc((void**)&out1, Mp * N * 2));
-    DD_TRY(hipMalloc((void**)&bias, (size_t)N * 4));
-    DD_TRY(hipMalloc((void**)&x0, Mp * N * 4));
-    DD_TRY(hipMalloc((void**)&x1, Mp * N * 4));
-    DD_TRY(launch_fill_random<bf16_t>(A, (long long)Mp * K, 1u, 1.0f, s));
-    DD_TRY(launch_fill_random<bf16_t>(W, (long long)N * K, 2u, 0.05f, s));
-    DD_TRY(launch_fill_random<float>(bias, N, 3u, 0.1f, s));
-    auto run = [&](int var, bf16_t* out, float* x) -> hipError_t {
-        GemmArgs<bf16_t> g{A, nullptr, W, bias, x, out, M, N, K, K, K, 0, N, var == variant ? (variant >> 8) : 0};
-        return launch_gemm_variant<bf16_t>(g, epilogue, var & 0xff, s);
-    };
-    long long mism = -1;
-    if (check) {
-        DD_TRY(launch_fill_random<float>(x0, (long long)Mp * N, 4u, 1.0f, s));
-        DD_TRY(launch_fill_random<float>(x1, (long long)Mp * N, 4u, 1.0f, s));
-        DD_TRY(hipMemsetAsync(out0, 0, Mp * N * 2, s));
-        DD_TRY(hipMemsetAsync(out1, 0, Mp * N * 2, s));
-        DD_TRY(run(0, out0, x0));
-        DD_TRY(run(variant, out1, x1));
-        DD_TRY(hipStreamSynchronize(s));
-        std::vector<unsigned short> h0((size_t)M * N), h1((size_t)M * N);
-        std::vector<float> f0, f1;
-        mism = 0;
-        if (epilogue != EPI_BIAS_SET) {
-            DD_TRY(hipMemcpy(h0.data(), out0, h0.size() * 2, hipMemcpyDeviceToHost));
-            DD_TRY(hipMemcpy(h1.data(), out1, h1.size() * 2, hipMemcpyDeviceToHost));
-            long long rb[8] = {0}, cb[8] = {0}, tb[8] = {0};
-            for (size_t i = 0; i < h0.size(); ++i) {
-                if (h0[i] != h1[i]) {
-                    ++mism;
-                    const size_t r = i / N, cc = i % N;
-                    ++rb[(r % 128) / 16]; ++cb[(cc % 128) / 16]; ++tb[((r / 128) * ((N + 127) / 128) + cc / 128) % 8];
-                }
-            }
-            if (mism && getenv("DD_DEBUG"))
-                fprintf(stderr, "mismatch rows/16 in tile: %lld %lld %lld %lld %lld %lld %lld %lld | cols/16: %lld %lld %lld %lld %lld %lld %lld %lld | tile%%8: %lld %lld %lld %lld %lld %lld %lld %lld\n",
-                        rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], rb[6], rb[7], cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], cb[6], cb[7],
-                        tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], tb[6], tb[7]);
-        }
-        if (epilogue >= EPI_BIAS_RESID) {
-            f0.resize((size_t)M * N); f1.resize((size_t)M * N);
-            DD_TRY(hipMemcpy(f0.data(), x0, f0.size() * 4, hipMemcpyDeviceToHost));
-            DD_TRY(hipMemcpy(f1.data(), x1, f1.size() * 4, hipMemcpyDeviceToHost));
-            mism += std::memcmp(f0.data(), f1.data(), f0.size() * 4) != 0 ? 1 : 0;
-        }
-    }
-    DD_TRY(run(variant, out1, x1));  // warm
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    DD_TRY(hipEventCreate(&e0));
-    DD_TRY(hipEventCreate(&e1));
-    DD_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) DD_TRY(run(variant, out1, x1));
-    DD_TRY(hipEventRecord(e1, s));
-    DD_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    DD_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if ((variant & 0xff) == 14) {   // development: cycle stamps of workgroup 0, waves 0 and 4 (gemm256_kernel<.., DEV=1>)
-        unsigned long long st[128];
-        DD_TRY(hipMemcpy(st, x1, sizeof(st), hipMemcpyDeviceToHost));
-        for (int w = 0; w < 2; ++w) {
-            fprintf(stderr, "stamps wave %d:", w * 4);
-            for (int i = 1; i < 30; ++i) fprintf(stderr, " %lld", (long long)(st[w * 64 + i] - st[w * 64 + i - 1]));
-            fprintf(stderr, "\n");
-        }
-    }
-#undef DD_TRY
-    cleanup();
-    *ms_out = ms / (float)iters;
-    if (mismatch_out) *mismatch_out = mism;
+    c->num_cus = n / 8 * 8;      // the persistent kernels deal tiles to workgroups in groups of 8 (one per XCD)
     return DD_OK;
 }
 

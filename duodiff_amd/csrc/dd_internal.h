@@ -66,15 +66,12 @@ struct GemmArgs {
     T* out;            // [Mp, ldo] or null
     int M, N, K, K1;
     int lda, lda2, ldo;
-    int ablate;        // development only: 1 skip epilogue memory traffic, 2 skip LDS-DMA after tile 0, 4 skip MFMA
 };
 
-template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s);
-template <typename T> hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s);
-void set_gemm_variant(int v);
-void set_gemm_num_cus(int n);
+// num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
+template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int num_cus);
 bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e);
-int get_gemm_variant();
+int device_num_cus();
 
 // ---- fused MLP (mlp_fused.hip): x += fc2(gelu(fc1(h) + b1)) + b2 in one launch
 struct MlpFusedArgs {

@@ -30,28 +30,8 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
-// exact-erf GELU (nn.GELU default).  fp32 parity mode: libm erff.  bf16 mode: the output is
-// rounded to bf16 (2^-9 relative) anyway, so erf comes from Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7 absolute) on v_rcp/v_exp: ~14 VALU ops instead of erff's ~45, which made
-// the fc1 epilogue, not the MFMA loop, the bound of that kernel.
-template <typename T>
-__device__ __forceinline__ float gelu_erf(float v) {
-    if constexpr (sizeof(T) == 4) {
-        return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    } else {
-        const float x = fabsf(v) * 0.70710678118654752440f;
-        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-        float p = fmaf(1.061405429f, t, -1.453152027f);
-        p = fmaf(p, t, 1.421413741f);
-        p = fmaf(p, t, -0.284496736f);
-        p = fmaf(p, t, 0.254829592f);
-        p *= t;
-        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
-        const float erf_abs = fmaf(-p, e, 1.0f);          // erf(|v|/sqrt2) in [0, 1]
-        const float erf_v = copysignf(erf_abs, v);
-        return 0.5f * v * (1.0f + erf_v);
-    }
-}
+// exact-erf GELU (nn.GELU default), fp32 parity mode: libm erff.  (The bf16 mode uses the polynomial of gelu_erf4.)
+__device__ __forceinline__ float gelu_erf_f32(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // Stage ROWS x 128 B into a lane-linear LDS tile with the source-side chunk swizzle.
 // `g` points at (row 0, this k-tile's first byte); rows >= row_limit are clamped (N guard).
@@ -76,7 +56,7 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
     if constexpr (sizeof(T) == 4) {
         f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = gelu_erf<T>(v[e]);
+        for (int e = 0; e < 4; ++e) r[e] = gelu_erf_f32(v[e]);
         return r;
     } else {
         // bf16 mode: the result is rounded to bf16 (2^-9 relative), so erf(v/sqrt2) comes from an odd minimax polynomial
@@ -168,7 +148,6 @@ gemm_kernel(const GemmArgs<T> a) {
     const long long sw = (long long)a.K * sizeof(T);
 
     auto stage = [&](int kt, int buf) {
-        if ((a.ablate & 2) && kt > 0) return;
         char* at = smem + buf * STAGE_BYTES;
         if (kt < nk1) stage_tile<BM, NW>(A1 + (long long)kt * 128, sa1, at, wave, lane, BM);
         else stage_tile<BM, NW>(A2 + (long long)(kt - nk1) * 128, sa2, at, wave, lane, BM);
@@ -184,7 +163,6 @@ gemm_kernel(const GemmArgs<T> a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto compute = [&](int buf) {
-        if (a.ablate & 4) return;
         const char* Ab = smem + buf * STAGE_BYTES + (wr * (BM / WM)) * 128;
         const char* Bb = smem + buf * STAGE_BYTES + A_BYTES + (wc * (BN / WN)) * 128;
 #pragma unroll
@@ -302,7 +280,6 @@ gemm_kernel(const GemmArgs<T> a) {
             }
         }
     };
-    if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) return;
     // interior tiles (block-uniform test) skip every per-element bound check
     if (m0 + BM <= a.M && n0 + BN <= a.N) epilogue(std::false_type{});
     else epilogue(std::true_type{});
@@ -350,7 +327,7 @@ constexpr int k256Stage = (k256ARows + 256) * 128;               // 66560 B
 constexpr int k256BiasOff = 2 * k256Stage;                       // two 1 KB bias slots (tile parity)
 constexpr int k256Lds = k256BiasOff + 2 * 1024;                  // 135168 B
 
-template <int EPI, int DEV = 0>   // DEV 1: s_memtime stamps of wave 0 / 4 of workgroup 0 into xres (development only)
+template <int EPI>
 __global__ void __launch_bounds__(512)
 gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     typedef bf16_t T;
@@ -373,16 +350,6 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     if (n_my == 0) return;
 
     const int nk = a.K >> 6, nk1 = a.K1 >> 6;
-    unsigned long long* stamps = nullptr;
-    int n_stamp = 0;
-    auto stamp = [&]() {
-        if constexpr (DEV == 1) {
-            if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && n_stamp < 60)
-                stamps[(wave >> 2) * 64 + n_stamp] = __builtin_readcyclecounter();
-            ++n_stamp;
-        }
-    };
-    if constexpr (DEV == 1) stamps = reinterpret_cast<unsigned long long*>(a.xres);
     const long long sa1 = (long long)a.lda * 2, sw = (long long)a.K * 2;   // lda2 == lda (checked on the host)
 
     // LDS-DMA addressing: wave-uniform 64-bit base (SGPRs) + ONE 32-bit per-lane offset per operand.
@@ -390,8 +357,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     // must therefore fetch logical chunk (l&7) ^ ((r>>1)&7).  With r = 8*inst + lr that is
     // (l&7) ^ (lr>>1) for even inst and the same ^ 4 for odd inst, i.e. byte offset ^ 64: per-lane
     // address state is two VGPRs for the whole kernel (it used to be ~18 and got spilled).
-    auto stage = [&](int tm, int tn, int kt, int buf, int parity, bool first) {
-        if ((a.ablate & 2) && !first) return;
+    auto stage = [&](int tm, int tn, int kt, int buf, int parity) {
         // recomputed per call from an opaque copy of the lane id (4 VALU ops): kept live across the
         // k-loop these offsets were the registers the allocator chose to spill
         unsigned l = (unsigned)lane;
@@ -489,7 +455,6 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     // `prefetch` (the LDS-DMA of the next k-tile) is issued AFTER this k-tile's first fragment reads, so their
     // latency overlaps the 9-17 DMA instructions instead of following them.
     auto compute = [&](int buf, auto&& prefetch) {
-        if (a.ablate & 4) { prefetch(); return; }
         const unsigned st = smem_lds + buf * k256Stage;
         pin_offsets();
         Frags f0, f1;
@@ -560,7 +525,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                 for (int g = 0; g < 4; ++g) {
                     f32x4 q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     if (HAS_BIAS) q += bias[g];
-                    if (EPI == EPI_BIAS_GELU && !(a.ablate & 8)) q = gelu_erf4<T>(q);
+                    if (EPI == EPI_BIAS_GELU) q = gelu_erf4<T>(q);
                     if (RESID) q = xl[u & 1][g] + q;
                     if (WRITES_X) *xptr(i, j, g) = q;
                     v[j][g] = pack4(q);
@@ -580,10 +545,9 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(v[j][gp].x, v[j][gp + 1].x, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(v[j][gp].y, v[j][gp + 1].y, false, false);
                         const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        if (!(a.ablate & 16)) *reinterpret_cast<uint4*>(a.out + orow * a.ldo + col0 + j * 32 + 8 * gp + 8 * h) = o;
+                        *reinterpret_cast<uint4*>(a.out + orow * a.ldo + col0 + j * 32 + 8 * gp + 8 * h) = o;
                     }
             }
-            stamp();
         }
         // tail rows: lane = tail row index (valid below part.e), registers = this wave's 32 columns
         if (part.e > 0) {
@@ -610,8 +574,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
 
     int lin = tile_of(0);
     int tm = lin / n_tiles, tn = lin - tm * n_tiles;
-    stage(tm, tn, 0, 0, 0, true);
-    stamp();
+    stage(tm, tn, 0, 0, 0);
     int buf = 0;
     bool stores_in_flight = false;
     for (int i = 0; i < n_my; ++i) {
@@ -635,15 +598,12 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             compute(buf, [&]() {
-                if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1, false);
-                else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1, false);
+                if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1);
+                else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1);
             });
             buf ^= 1;
         }
-        if ((a.ablate & 1) && acc[0][0][0] != 12345.678f) { stores_in_flight = false; lin = lin_next; tm = tm_next; tn = tn_next; continue; }
-        stamp();
         epilogue(lin, i & 1);
-        stamp();
         stores_in_flight = true;
         lin = lin_next; tm = tm_next; tn = tn_next;
     }
@@ -683,12 +643,9 @@ hipError_t init_cfg() {
     return e;
 }
 
-int g_variant_bf16 = 8;  // 8 = persistent 256x256 (falls back to 0 for shapes it does not take)
-int g_num_cus = 256;
-
 // Row partition for gemm256 (see the kernel's header): q main tiles, e tail rows per tile, chosen to
 // minimise rounds over the CUs; returns false when the shape does not fit the kernel.
-bool plan256(int M, int N, int K, int K1, Part256& p) {
+bool plan256(int M, int N, int K, int K1, int num_cus, Part256& p) {
     if (N % 256 || K % 64 || K1 % 64 || M < 256 || (long long)K * 2 * 8 >= (1ll << 31)) return false;
     const int nt = N / 256;
     const int q_hi = M / 256, q_lo = (M + 263) / 264;
@@ -699,7 +656,7 @@ bool plan256(int M, int N, int K, int K1, Part256& p) {
         const int e = tail > 0 ? (tail + q - 1) / q : 0;
         if (e > 8) continue;
         const long long tiles = (long long)q * nt;
-        const double rounds = (double)((tiles + g_num_cus - 1) / g_num_cus);
+        const double rounds = (double)((tiles + num_cus - 1) / num_cus);
         const double cost = rounds * (e > 0 ? 1.125 : 1.0);
         if (cost < best - 1e-9) { best = cost; best_q = q; }
     }
@@ -711,11 +668,10 @@ bool plan256(int M, int N, int K, int K1, Part256& p) {
     return true;
 }
 
-hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipStream_t s, int dev = 0) {
+hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, int num_cus, hipStream_t s) {
     const int tiles = p.q * (a.N / 256);
-    int grid = g_num_cus;
-    if (tiles < grid) grid = (tiles + 7) / 8 * 8;   // multiple of 8 (XCD grouping)
-    if (dev == 1) { hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU, 1>), dim3(grid), dim3(512), k256Lds, s, a, p); return hipGetLastError(); }
+    int grid = num_cus;                             // a multiple of 8: the kernel groups workgroups by XCD (gx = G >> 3)
+    if (tiles < grid) grid = (tiles + 7) / 8 * 8;
 #define DD_LAUNCH(E)                                                                                  \
     {                                                                                                 \
         hipLaunchKernelGGL((gemm256_kernel<E>), dim3(grid), dim3(512), k256Lds, s, a, p);             \
@@ -732,17 +688,6 @@ hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipS
     return hipErrorInvalidValue;
 }
 
-// tile/pipeline variants (bf16); the fp32 parity mode always uses variant 0
-#define DD_VARIANTS(X)          \
-    X(0, 128, 128, 2, 2, 2)     \
-    X(1, 256, 128, 4, 2, 2)     \
-    X(2, 256, 128, 4, 2, 3)     \
-    X(3, 256, 256, 2, 4, 2)     \
-    X(4, 128, 256, 2, 4, 3)     \
-    X(5, 256, 256, 4, 2, 2)     \
-    X(6, 128, 128, 2, 2, 3)     \
-    X(7, 128, 128, 2, 2, 4)
-
 }  // namespace
 
 // dynamic-LDS opt-in for every instantiation, once per process (kept out of the launch path so
@@ -750,72 +695,49 @@ hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, hipS
 hipError_t init_gemm_kernels() {
     hipError_t e = init_cfg<float, 128, 128, 2, 2, 2>();
     if (e == hipSuccess) e = init_cfg<float, 128, 64, 2, 2, 2>();
-#define X(ID, BM, BN, WM, WN, ST) \
-    if (e == hipSuccess) e = init_cfg<bf16_t, BM, BN, WM, WN, ST>();
-    DD_VARIANTS(X)
-#undef X
+    if (e == hipSuccess) e = init_cfg<bf16_t, 128, 128, 2, 2, 2>();
 #define DD_ATTR(E)                                                                                  \
     if (e == hipSuccess)                                                                            \
         e = hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
     DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE)
 #undef DD_ATTR
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS_GELU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return e;
 }
 
-void set_gemm_variant(int v) { g_variant_bf16 = v; }
+// CU count the persistent grids are sized for: the device's, rounded down to a multiple of 8 (the kernel assumes it)
+int device_num_cus() {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+        n = prop.multiProcessorCount;
+    return n / 8 * 8;
+}
+
 bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e) {
-    const int saved = g_num_cus;
-    if (num_cus > 0) g_num_cus = num_cus;
     Part256 p{};
-    const bool ok = plan256(M, N, K, K, p);
-    g_num_cus = saved;
+    const bool ok = plan256(M, N, K, K, num_cus >= 8 ? num_cus / 8 * 8 : 256, p);
     if (ok) { *q = p.q; *e = p.e; }
     return ok;
 }
-void set_gemm_num_cus(int n) { if (n >= 8) g_num_cus = n / 8 * 8; }
-int get_gemm_variant() { return g_variant_bf16; }
-int gemm_num_cus() { return g_num_cus; }
 
+// bf16: the persistent 256x256 kernel where the shape fits it, else the generic 128x128 kernel; fp32 (parity mode, exact
+// f32 MFMA): generic kernel.  num_cus sizes the persistent grid (per context: dd_set_num_cus).
 template <typename T>
-hipError_t launch_gemm_variant(const GemmArgs<T>& a, int epilogue, int variant, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int num_cus) {
     constexpr int KT = 128 / (int)sizeof(T);
     if (a.K % KT || a.K1 % KT || a.K1 > a.K || (a.K1 < a.K && !a.A2)) return hipErrorInvalidValue;
     if constexpr (sizeof(T) == 4) {
         if (a.N <= 64) return launch_cfg<T, 128, 64, 2, 2, 2>(a, epilogue, s);  // decoder_pred: N = P*P*C <= 64
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
     } else {
-        if (variant == 14) {
-            Part256 p;
-            if (plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, EPI_BIAS_GELU, p, s, 1);
-        }
-        if (variant == 8) {
-            Part256 p;
-            if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, p)) return launch_256(a, epilogue, p, s);
-            variant = 0;  // shapes the 256x256 kernel does not take (small N, tiny M)
-        }
-        switch (variant) {
-#define X(ID, BM, BN, WM, WN, ST) \
-    case ID: return launch_cfg<T, BM, BN, WM, WN, ST>(a, epilogue, s);
-            DD_VARIANTS(X)
-#undef X
-        }
-        return hipErrorInvalidValue;
+        Part256 p;
+        const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
+        if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
+        return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);   // shapes the 256x256 kernel does not take (small N, tiny M)
     }
 }
 
-template <typename T>
-hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s) {
-    return launch_gemm_variant<T>(a, epilogue, g_variant_bf16, s);
-}
-
-template hipError_t launch_gemm_variant<bf16_t>(const GemmArgs<bf16_t>&, int, int, hipStream_t);
-template hipError_t launch_gemm_variant<float>(const GemmArgs<float>&, int, int, hipStream_t);
-template hipError_t launch_gemm<bf16_t>(const GemmArgs<bf16_t>&, int, hipStream_t);
-template hipError_t launch_gemm<float>(const GemmArgs<float>&, int, hipStream_t);
+template hipError_t launch_gemm<bf16_t>(const GemmArgs<bf16_t>&, int, hipStream_t, int);
+template hipError_t launch_gemm<float>(const GemmArgs<float>&, int, hipStream_t, int);
 
 }  // namespace dd

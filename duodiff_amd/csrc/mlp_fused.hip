@@ -282,11 +282,14 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         __syncthreads();   // (vmcnt(0): the prologue blocks have landed; bias table, vectors and zero block are visible)
         // k-step ks of fc1 = registers 8 (ks & 1) .. + 7 of tile ks >> 1: element j is column
         // 16 ks + 8 (j >> 2) + 4 h + (j & 3) -- the permuted k order the W1 image is packed in (mlp_fused_pack, kperm)
+        constexpr int LB = C::NT < 2 ? C::NT : 2;     // (hidden-split tiles) look-ahead of the second read of the row
+        const float* xr2 = xr;
+        asm volatile("" : "+v"(xr2));                // opaque: hipcc otherwise keeps the 16 tile addresses of the first pass alive (spills)
         if constexpr (PARTIAL) {
 #pragma unroll
-            for (int t = 0; t < LA - 1; ++t)
+            for (int t = 0; t < LB - 1; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xq[t][g] = *reinterpret_cast<const f32x4*>(xr + 32 * t + 8 * g);
+                for (int g = 0; g < 4; ++g) xq[t][g] = *reinterpret_cast<const f32x4*>(xr2 + 32 * t + 8 * g);
         }
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
@@ -294,15 +297,15 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             if constexpr (!PARTIAL) {
                 yt = Y[t];                           // ONE copy of the tile out of the AGPRs (element-wise access re-reads all 16)
             } else {                                 // hidden-split tiles: the accumulators hold zeros, re-read the row (L1 / L2)
-                if (t + LA - 1 < C::NT) {
+                if (t + LB - 1 < C::NT) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) xq[(t + LA - 1) % LA][g] = *reinterpret_cast<const f32x4*>(xr + 32 * (t + LA - 1) + 8 * g);
+                    for (int g = 0; g < 4; ++g) xq[(t + LB - 1) % LB][g] = *reinterpret_cast<const f32x4*>(xr2 + 32 * (t + LB - 1) + 8 * g);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) yt[4 * g + e] = xq[t % LA][g][e];
+                    for (int e = 0; e < 4; ++e) yt[4 * g + e] = xq[t % LB][g][e];
             }
 #pragma unroll
             for (int kq = 0; kq < 2; ++kq) {

@@ -19,7 +19,7 @@ using namespace dd;
 
 struct dd_ctx;
 extern "C" const char* dd_last_error(dd_ctx*);
-namespace dd { int ctx_fail(dd_ctx* c, int code, const std::string& msg); int ctx_device(dd_ctx* c); }
+namespace dd { int ctx_fail(dd_ctx* c, int code, const std::string& msg); int ctx_device(dd_ctx* c); int ctx_num_cus(dd_ctx* c); }
 
 namespace {
 
@@ -104,7 +104,7 @@ int run_decode(dd_vae* v, const float* z, float* out, int B, int HL, hipStream_t
 
     auto gemm = [&](const T* A, int M, int K, const ConvW& w, int epi, float* xres, T* o, int ldo) -> int {
         GemmArgs<T> g{A, nullptr, (const T*)w.w, w.b, xres, o, M, w.cout == 3 ? 4 : w.cout, K, K, K, 0, ldo};
-        VHIP(c, launch_gemm<T>(g, epi, s));
+        VHIP(c, launch_gemm<T>(g, epi, s, ctx_num_cus(c)));
         return DD_OK;
     };
     // 3x3 conv of the T-typed NHWC image `src` (C channels at Hs x Hs, optionally upsampled 2x first)
@@ -151,16 +151,16 @@ int run_decode(dd_vae* v, const float* z, float* out, int B, int HL, hipStream_t
             const T* hb = nb + (long long)b * HW * C;
             // V^T[c][tok] = Wv[c][:] . h[tok][:]  (bias of v is added after P.V: softmax rows sum to 1)
             GemmArgs<T> gv{(const T*)v->attn_v.w, nullptr, hb, nullptr, nullptr, (T*)v->vt, C, HW, C, C, C, 0, HW};
-            VHIP(c, launch_gemm<T>(gv, EPI_STORE, s));
+            VHIP(c, launch_gemm<T>(gv, EPI_STORE, s, ctx_num_cus(c)));
             // S[i][j] = q_i . k_j  -> fp32
             GemmArgs<T> gs{(const T*)v->q + (long long)b * HW * C, nullptr, (const T*)v->kk + (long long)b * HW * C, nullptr,
                            v->score, nullptr, HW, HW, C, C, C, 0, 0};
-            VHIP(c, launch_gemm<T>(gs, EPI_BIAS_SET, s));
+            VHIP(c, launch_gemm<T>(gs, EPI_BIAS_SET, s, ctx_num_cus(c)));
             VHIP(c, launch_softmax_rows<T>(v->score, (T*)v->pp, HW, HW, 1.0f / sqrtf((float)C), s));
             // O[i][c] = sum_j P[i][j] V^T[c][j] + b_v[c]
             GemmArgs<T> go{(const T*)v->pp, nullptr, (const T*)v->vt, v->attn_v.b, v->ao + (long long)b * HW * C, nullptr,
                            HW, C, HW, HW, HW, 0, 0};
-            VHIP(c, launch_gemm<T>(go, EPI_BIAS_SET, s));
+            VHIP(c, launch_gemm<T>(go, EPI_BIAS_SET, s, ctx_num_cus(c)));
         }
         VHIP(c, launch_cast<T>(v->ao, (T*)v->q, (long long)M * C, s));
         if ((rc = gemm((const T*)v->q, M, C, v->attn_proj, EPI_BIAS_RESID, cur, nullptr, 0))) return rc;  // x + proj_out(h_)

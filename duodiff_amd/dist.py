@@ -28,7 +28,8 @@ def init(backend: Optional[str] = None):
         return rank, world, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # DUODIFF_DIST_BACKEND=gloo forces the CPU transport (rehearsing N ranks on one GPU; tests)
+        backend = os.environ.get("DUODIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -52,6 +53,8 @@ def gather_images(local: torch.Tensor, world: int, dst: Optional[int] = None):
     if world == 1:
         return local
     local = local.contiguous()
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()          # gloo moves host memory; the payload is one image batch per >= 1000 steps
     if dst is None:
         out = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(out, local)
@@ -93,7 +96,7 @@ def main(argv=None):
     args = sampler.get_args(argv)
     rank, world, local_rank = init()
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())   # (ranks may share a GPU when rehearsed on one)
     config = sampler.load_config(args.config_path)
     model, mp = sampler.build_model(config, args.checkpoint_path, args.precision, args.batch_size)
     late = None

@@ -116,15 +116,9 @@ class Context:
                                            float(c), _ptr(out), x.numel(), _stream_ptr(stream)))
         return out
 
-    def dev_gemm(self, M, N, K, variant=0, epilogue=0, iters=20, check=False, stream=None):
-        """Development harness: time one bf16 GEMM variant; returns (ms, TFLOP/s, mismatches vs variant 0)."""
-        ms, mm = C.c_float(), C.c_longlong()
-        self.check(self.lib.dd_dev_gemm(self.handle, M, N, K, variant, epilogue, iters, int(check),
-                                        _stream_ptr(stream), C.byref(ms), C.byref(mm)))
-        return ms.value, 2.0 * M * N * K / (ms.value * 1e-3) / 1e12, mm.value
-
-    def set_gemm_variant(self, variant):
-        self.check(self.lib.dd_set_gemm_variant(self.handle, int(variant)))
+    def set_num_cus(self, n):
+        """CU count this context's persistent GEMM grids are sized for (CU-masked streams)."""
+        self.check(self.lib.dd_set_num_cus(self.handle, int(n)))
 
     def last_sample_timing(self):
         buf = (C.c_float * 3)()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 typedef struct dd_ctx dd_ctx;
 typedef struct dd_model dd_model;
@@ -193,41 +193,27 @@ int dd_vae_decode(dd_ctx* ctx, dd_vae* v, const float* z_dev, float* out_dev, in
 void dd_vae_destroy(dd_vae* v);
 
 /* ---- measurement support ------------------------------------------------------------ */
-/* Time `iters` back-to-back launches of the engine's dominant kernel (the fc1 GEMM of
- * model m at batch B, fused bias+GELU epilogue) with hipEvents on `stream`.
- * Returns average milliseconds per launch in *ms_out and the launch's algorithmic FLOPs. */
+/* Time `iters` back-to-back launches of the fc1 GEMM (fused bias+GELU epilogue) of model m at batch B with hipEvents
+ * on `stream`: the dominant kernel of the two-GEMM MLP path (fp32 mode, D > 512; bf16 models with D <= 512 run the fused
+ * MLP kernel instead, timed in context by dd_profile_steps).  Returns average milliseconds per launch in *ms_out and
+ * the launch's algorithmic FLOPs. */
 int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
                   float* ms_out, double* flops_out);
 /* In-context timing of the dominant kernel: runs `steps` eager sampling steps (t = t_start, t_start-1, ...) in place
- * on x_dev with a hipEvent pair recorded on `stream` around EVERY fc1 GEMM launch (depth launches per step), and returns
- * the average milliseconds per launch -- the same thing rocprofv3 --kernel-trace averages for that kernel. */
+ * on x_dev with a hipEvent pair recorded on `stream` around EVERY launch of the block's MLP (depth per step) -- the fused
+ * MLP kernel (norm2 + fc1 + GELU + fc2 + residual + next norm1, incl. its small reduce launch) where the model uses it,
+ * else the fc1 GEMM -- and returns the average milliseconds per launch: what rocprofv3 --kernel-trace averages. */
 int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
                      void* stream, float* fc1_ms_out, int* launches_out);
-
-/* Development harness: one bf16 GEMM  C[M,N] = A[M,K] W[N,K]^T  on pseudo-random operands with
- * tile/pipeline `variant` and fused `epilogue` (0 store, 1 bias+GELU, 2 bias+residual, 3 bias+set),
- * `iters` timed launches (hipEvents on `stream`).  *mismatch_out = number of output elements that
- * differ bitwise from variant 0 (all variants accumulate k in the same order), or -1 if check==0. */
-int dd_dev_gemm(dd_ctx* ctx, int M, int N, int K, int variant, int epilogue, int iters, int check,
-                void* stream, float* ms_out, long long* mismatch_out);
-/* Development harness for the fused MLP kernel: x += fc2(gelu(fc1(bf16(h)) + b1)) + b2 on host arrays (h [M,D], nn.Linear
- * weights fp32, xres_host [M,D] in/out, out_host optional bf16 copy), plus `iters` timed launches.  extras == 0: the
- * rows are one image of M patch tokens; extras > 0: M / (1 + extras) images of `extras` extra tokens + 1 patch token.
- * ln_in [2, D] (gamma, beta) or NULL: the kernel's fused-LayerNorm prologue is used, h = LayerNorm(xres) (h_host ignored);
- * ln_out [2, D] + ln_out_host [M, D] bf16 or NULL: LayerNorm of the updated rows from the epilogue. */
-int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
-               const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
-               const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out);
-/* Select the GEMM variant the engine uses for bf16 models (default 0). */
-int dd_set_gemm_variant(dd_ctx* ctx, int variant);
 
 /* Host-only: the row partition the 256x256 GEMM uses for C[M,N] = A[M,K] W[N,K]^T on `num_cus` CUs:
  * q main tiles of 256 rows + e (<= 8) tail rows per tile; DD_ERR_UNSUPPORTED if the shape falls back
  * to the generic 128x128 kernel.  Needs no GPU. */
 int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out);
 
-/* Number of CUs the persistent GEMM grids are sized for (default: the device's CU count).  For callers
- * that run the engine on a CU-masked stream (hipExtStreamCreateWithCUMask). */
+/* Number of CUs this context's persistent GEMM grids are sized for (default: the device's CU count, rounded down to
+ * a multiple of 8; any value is rounded likewise).  For callers that run the engine on a CU-masked stream
+ * (hipExtStreamCreateWithCUMask). */
 int dd_set_num_cus(dd_ctx* ctx, int num_cus);
 
 /* Per-step timing of the last dd_sample call, measured with hipEvents on its stream:

@@ -1,0 +1,26 @@
+/*
+ * duodiff_dev.h -- development / validation entry points of libduodiff.so.  NOT part of the drop-in boundary
+ * (include/duodiff.h): nothing on the reference side binds these; tests and tools use them to drive one kernel alone.
+ */
+#ifndef DUODIFF_DEV_H
+#define DUODIFF_DEV_H
+
+#include "duodiff.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Development harness for the fused MLP kernel: x += fc2(gelu(fc1(bf16(h)) + b1)) + b2 on host arrays (h [M,D], nn.Linear
+ * weights fp32, xres_host [M,D] in/out, out_host optional bf16 copy), plus `iters` timed launches.  extras == 0: the
+ * rows are one image of M patch tokens; extras > 0: M / (1 + extras) images of `extras` extra tokens + 1 patch token.
+ * ln_in [2, D] (gamma, beta) or NULL: the kernel's fused-LayerNorm prologue is used, h = LayerNorm(xres) (h_host ignored);
+ * ln_out [2, D] + ln_out_host [M, D] bf16 or NULL: LayerNorm of the updated rows from the epilogue. */
+int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
+               const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUODIFF_DEV_H */

@@ -78,3 +78,26 @@ def test_single_process_path_is_a_no_op():
     assert ddist.init() == (0, 1, 0)
     g, local = ddist.sample_sharded(_sample, base_seed=40)
     assert torch.equal(g, local) and ddist.rank_seed(40, 3) == 43
+
+
+def test_bench_launch_plumbing_reaches_the_process_group(tmp_path):
+    """bench.py under the driver's multi-GPU launch (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun): both ranks
+    must reach init_process_group and agree on the world.  On this box there is no GPU, so the transport is forced to
+    gloo and each rank then stops loudly at the engine (no CPU path) -- which is exactly the plumbing under test."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DUODIFF_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                                      cwd=str(REPO), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert f"process group initialised: rank {rank} of world 2, backend gloo" in se, se[-2000:]
+        if not torch.cuda.is_available():
+            assert p.returncode != 0 and "no CPU path" in se          # loud failure, no silent fallback
+    # a world/--gpus mismatch is refused before anything else happens
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"], cwd=str(REPO), capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, timeout=300)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)

@@ -39,7 +39,7 @@ def _oracle(cfg, seed):
 def test_library_loaded_in_tree():
     from duodiff_amd import _lib
     lib = _lib.load()
-    assert str(_lib.LIB_PATH).endswith("duodiff_amd/libduodiff.so") and lib.dd_abi_version() == 1
+    assert str(_lib.LIB_PATH).endswith("duodiff_amd/libduodiff.so") and lib.dd_abi_version() == 2
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -466,3 +466,40 @@ def test_full_batch_vs_oracle(name, B):
         err = np.abs(eps[i:i + 1] - want).max()
         print(f"{name} B={B} image {i}: max|eps - oracle| = {err:.3e} (std {want.std():.3f})")
         assert err <= EPS_TOL["bf16"]
+
+
+def test_two_ranks_equal_two_single_rank_runs(tmp_path):
+    """Engine-level multi-GPU contract on one GPU: two fresh processes run `python -m duodiff_amd.dist` as ranks 0 / 1 of a
+    world of 2 (transport forced to gloo, both on this GPU; the driver runs the RCCL path on the 8-GPU node).  The
+    gathered images must equal, bit for bit, the two single-rank runs with seeds base and base + 1, in rank order."""
+    import os, socket, subprocess, sys, yaml
+    from duodiff_amd import sampler
+    cfg_s, cfg_f = dict(TINY, depth=1, img_size=16), dict(TINY, depth=3, img_size=16)
+    for name, cfg, seed in (("s", cfg_s, 21), ("f", cfg_f, 22)):
+        (tmp_path / f"{name}.yaml").write_text(yaml.safe_dump({"model_params": dict(cfg)}))
+        torch.save(dict(synthetic_state_dict(ModelParams.from_dict(cfg), seed)), tmp_path / f"{name}.pth")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "out"
+    base, B = 11, 3
+    cmd = [sys.executable, "-m", "duodiff_amd.dist", "--seed", str(base), "--checkpoint_path", str(tmp_path / "s.pth"),
+           "--checkpoint_path_late", str(tmp_path / "f.pth"), "--config_path", str(tmp_path / "s.yaml"),
+           "--config_path_late", str(tmp_path / "f.yaml"), "--t_switch", "300", "--batch_size", str(B),
+           "--parametrization", "predict_noise", "--output_folder", str(out), "--no_png", "--precision", "bf16", "--noise", "device"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DUODIFF_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(cmd, cwd=str(REPO), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+    got = np.load(out / "samples.npy")
+    assert got.shape == (2 * B, 16, 16, 3) and np.isfinite(got).all()
+    m_s, _ = _uvit(cfg_s, 21, "bf16")
+    m_f, _ = _uvit(cfg_f, 22, "bf16")
+    for r in range(2):
+        want, _ = sampler.get_samples(m_s, B, sampler.predict_noise_postprocessing, base + r, 3, 16, 16, late_model=m_f,
+                                      t_switch=300, noise="device")
+        assert np.array_equal(got[r * B:(r + 1) * B], want), f"rank {r} shard differs from the single-rank run with seed {base + r}"

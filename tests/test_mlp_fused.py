@@ -1,0 +1,95 @@
+"""GPU unit tests of the fused MLP kernel (csrc/mlp_fused.hip) through its development entry point dd_dev_mlp
+(include/duodiff_dev.h): x += fc2(GELU_erf(fc1(LayerNorm(x)))) against a float64 reference built from the SAME
+bf16-rounded operands, so the tolerance only has to cover the kernel's own arithmetic (bf16 rounding of the hidden
+activation, the GELU polynomial's 2.4e-4, fp32 accumulation order) -- not the bf16 quantisation of the inputs.
+Covers: every supported width, ragged last tiles, the extra-token rows (hidden-split path + reduce kernel), the fused
+LayerNorm prologue / epilogue, and the bf16 copy.  Replaces reference models/uvit.py:86-92, 206-207.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _layernorm(x, gb):
+    x = x.astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return ((x - mu) / np.sqrt(var + 1e-5) * gb[0] + gb[1]).astype(np.float32)
+
+
+def _reference(h, w1, b1, w2, b2, x):
+    from scipy.special import erf
+    s = _bf16(h).astype(np.float64) @ _bf16(w1).astype(np.float64).T + b1.astype(np.float64)
+    g = 0.5 * s * (1.0 + erf(s / np.sqrt(2.0)))                      # nn.GELU() default: exact erf
+    return x.astype(np.float64) + _bf16(g.astype(np.float32)).astype(np.float64) @ _bf16(w2).astype(np.float64).T + b2.astype(np.float64)
+
+
+@pytest.mark.parametrize("M,D,extras,ln", [
+    (300, 512, 0, True), (128, 512, 0, False), (700, 512, 1, True), (257 * 3, 512, 2, True),
+    (40, 64, 0, True), (900, 64, 2, True), (700, 128, 1, False), (1500, 256, 0, True)])
+def test_fused_mlp_against_float64_reference(M, D, extras, ln):
+    from duodiff_amd.engine import Context
+    ctx = Context.get()
+    hidden = 4 * D
+    g = np.random.default_rng(M + D)
+    h = g.standard_normal((M, D), dtype=np.float32)
+    w1 = (g.standard_normal((hidden, D), dtype=np.float32) * 0.05).astype(np.float32)
+    b1 = (g.standard_normal(hidden, dtype=np.float32) * 0.2).astype(np.float32)
+    w2 = (g.standard_normal((D, hidden), dtype=np.float32) * 0.05).astype(np.float32)
+    b2 = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x = (g.standard_normal((M, D), dtype=np.float32) * 1.5 + 0.3).astype(np.float32)
+    ln_in = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ln_out = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    if ln:
+        h = _layernorm(x, ln_in)                      # what the kernel's prologue computes itself from x
+    want = _reference(h, w1, b1, w2, b2, x)
+    got, out, hout = x.copy(), np.zeros((M, D), np.uint16), np.zeros((M, D), np.uint16)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    ms = C.c_float(0)
+    ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
+                                 P(ln_in) if ln else None, P(ln_out) if ln else None, P(hout) if ln else None, 0,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms)))
+    scale = float(np.abs(want - x).std())             # size of the MLP's contribution
+    err = np.abs(got - want)
+    print(f"M={M} D={D} extras={extras} ln={ln}: max {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (mlp std {scale:.3f})")
+    assert np.isfinite(got).all()
+    assert err.max() <= 1.5e-2 * max(scale, 0.1) and np.sqrt((err ** 2).mean()) <= 2e-3 * max(scale, 0.1)
+    as_f32 = lambda u: torch.from_numpy(u.view(np.int16)).view(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(as_f32(out), _bf16(got))    # the bf16 copy is the rounding of what was stored
+    if ln:                                            # next block's norm1 of the updated rows, bf16
+        assert np.abs(as_f32(hout) - _layernorm(got, ln_out)).max() <= 4e-2
+
+
+def test_fused_mlp_rows_do_not_depend_on_their_neighbours():
+    """Which path a row takes (main tile / hidden-split) depends only on its token index, so the same row inside two
+    different batches gives bit-identical results (the engine-level statement: test_batch_independence_at_full_size)."""
+    from duodiff_amd.engine import Context
+    ctx = Context.get()
+    D, hidden, extras = 512, 2048, 1
+    g = np.random.default_rng(7)
+    w1 = (g.standard_normal((hidden, D), dtype=np.float32) * 0.05).astype(np.float32)
+    b1 = np.zeros(hidden, np.float32)
+    w2 = (g.standard_normal((D, hidden), dtype=np.float32) * 0.05).astype(np.float32)
+    b2 = np.zeros(D, np.float32)
+    ln = np.stack([np.ones(D), np.zeros(D)]).astype(np.float32)
+    x_all = g.standard_normal((400, D), dtype=np.float32)             # 200 "images" of 1 extra + 1 patch token
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(x):
+        got, hout = x.copy(), np.zeros(x.shape, np.uint16)
+        ms = C.c_float(0)
+        ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, x.shape[0], D, hidden, extras, P(x), P(w1), P(b1), P(w2), P(b2), P(got), None,
+                                     P(ln), P(ln), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms)))
+        return got, hout
+
+    big, hbig = run(x_all)
+    small, hsmall = run(x_all[:6].copy())
+    assert np.array_equal(big[:6], small) and np.array_equal(hbig[:6], hsmall)
