@@ -18,7 +18,7 @@ ABI_VERSION = 2
 class dd_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads", "mlp_ratio",
-        "num_classes", "normalize_timesteps", "max_batch")]
+        "num_classes", "normalize_timesteps", "max_batch", "qkv_bias", "mlp_time_embed")]
 
 
 class dd_sample_args(C.Structure):
@@ -65,7 +65,7 @@ SIGNATURES = {
     "dd_vae_destroy": (None, [C.c_void_p]),
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
-    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 3),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_plan_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dd_last_sample_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

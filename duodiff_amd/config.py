@@ -64,10 +64,6 @@ class ModelParams:
             raise ValueError("embed_dim must be a multiple of num_heads")
         if self.depth % 2 != 1:
             raise ValueError("depth must be odd (depth//2 in-blocks, mid, depth//2 out-blocks)")
-        if self.mlp_time_embed:
-            raise NotImplementedError("mlp_time_embed=True is not used by any shipped config")
-        if self.qkv_bias:
-            raise NotImplementedError("qkv_bias=True is not used by any shipped config")
 
     # derived sizes
     @property

@@ -47,7 +47,7 @@ struct HostParam {
 };
 
 struct BlockW {
-    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *proj_b, *fc1_b, *fc2_b, *skip_b;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *proj_b, *fc1_b, *fc2_b, *skip_b, *qkv_b;
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w, *skip_w;
     const char* mlp_img;     // fused-MLP weight image (mlp_fused.hip) or null
     const float* mlp_b1p;    // fc1 bias in accumulator-register order
@@ -76,6 +76,7 @@ struct dd_model {
     char* wsarena = nullptr;   // activations
     std::vector<BlockW> blocks;  // in.., mid, out..
     const float *emb_wt = nullptr, *emb_b = nullptr, *pos = nullptr, *label = nullptr;
+    const float *tm_w1t = nullptr, *tm_b1 = nullptr, *tm_w2t = nullptr, *tm_b2 = nullptr;   // time_embed MLP (mlp_time_embed)
     const float *norm_g = nullptr, *norm_b = nullptr, *wdec = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
     float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
     std::vector<void*> skips;
@@ -85,6 +86,7 @@ struct dd_model {
     std::vector<HeadW> heads;             // head i is applied to the input of block i
     const float *probe_w = nullptr, *probe_b = nullptr;   // [n_probe, D], [n_probe]
     bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
+    bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph = nullptr;
@@ -226,6 +228,12 @@ bool expected_shape(const dd_model* m, const std::string& name, std::vector<int6
     if (is("pos_embed")) { shp = {1, m->L, D}; return true; }
     if (is("patch_embed.proj.weight")) { shp = {D, C, P, P}; return true; }
     if (is("patch_embed.proj.bias")) { shp = {D}; return true; }
+    if (m->cfg.mlp_time_embed) {
+        if (is("time_embed.0.weight")) { shp = {4 * D, D}; return true; }
+        if (is("time_embed.0.bias")) { shp = {4 * D}; return true; }
+        if (is("time_embed.2.weight")) { shp = {D, 4 * D}; return true; }
+        if (is("time_embed.2.bias")) { shp = {D}; return true; }
+    }
     if (is("label_emb.weight")) { if (m->cfg.num_classes <= 0) return false; shp = {m->cfg.num_classes, D}; return true; }
     if (is("norm.weight") || is("norm.bias")) { shp = {D}; return true; }
     if (is("decoder_pred.weight")) { shp = {m->pd, D}; return true; }
@@ -275,6 +283,7 @@ bool expected_shape(const dd_model* m, const std::string& name, std::vector<int6
     if (rest == "norm1.weight" || rest == "norm1.bias" || rest == "norm2.weight" || rest == "norm2.bias" ||
         rest == "attn.proj.bias" || rest == "mlp.fc2.bias") { shp = {D}; return true; }
     if (rest == "attn.qkv.weight") { shp = {3 * D, D}; return true; }
+    if (m->cfg.qkv_bias && rest == "attn.qkv.bias") { shp = {3 * D}; return true; }
     if (rest == "attn.proj.weight") { shp = {D, D}; return true; }
     if (rest == "mlp.fc1.weight") { shp = {hid, D}; return true; }
     if (rest == "mlp.fc1.bias") { shp = {hid}; return true; }
@@ -289,12 +298,15 @@ std::vector<std::string> required_names(const dd_model* m) {
                                   "norm.bias", "decoder_pred.weight", "decoder_pred.bias", "final_layer.weight",
                                   "final_layer.bias"};
     if (m->cfg.num_classes > 0) v.push_back("label_emb.weight");
+    if (m->cfg.mlp_time_embed)
+        for (const char* s : {"time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"}) v.push_back(s);
     auto blk = [&](const std::string& p, bool skip) {
         for (const char* s : {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.proj.weight", "attn.proj.bias",
                               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
                               "mlp.fc2.bias"})
             v.push_back(p + s);
         if (skip) { v.push_back(p + "skip_linear.weight"); v.push_back(p + "skip_linear.bias"); }
+        if (m->cfg.qkv_bias) v.push_back(p + "attn.qkv.bias");
     };
     for (int i = 0; i < m->half_depth; ++i) blk("in_blocks." + std::to_string(i) + ".", false);
     blk("mid_block.", false);
@@ -318,6 +330,18 @@ std::vector<std::string> required_names(const dd_model* m) {
 // early-exit taps of one forward (EarlyExitUViT.forward, early_exit.py:290-313): cls [depth, B], outs [depth, B, C, S, S]
 struct EeTaps { float* cls; float* outs; int t; };
 
+// attn.proj + bias + residual of the extra-token rows only (rows l < extras of each image, stride L): the rows the fused
+// kernel's main tiles do not cover.  One small strided GEMM per extra token.
+hipError_t proj_extra_rows(const bf16_t* ao, const bf16_t* wproj, const float* bproj, float* x, int B, int L, int extras, int D,
+                           hipStream_t s, int num_cus) {
+    for (int l = 0; l < extras; ++l) {
+        GemmArgs<bf16_t> g{ao + (size_t)l * D, nullptr, wproj, bproj, x + (size_t)l * D, nullptr, B, D, D, D, L * D, 0, D, L * D};
+        const hipError_t e = launch_gemm<bf16_t>(g, EPI_BIAS_RESID, s, num_cus);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 template <typename T>
 int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s,
                  const EeTaps* ee = nullptr) {
@@ -328,6 +352,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, D, L, m->extras,
                  m->cfg.num_classes, m->cfg.normalize_timesteps, Mp};
     DD_HIP(c, launch_embed(ea, s));
+    if (m->tm_w1t) {   // mlp_time_embed: the time token goes through Linear -> SiLU -> Linear (models/uvit.py:264-272, 358)
+        TimeMlpArgs ta{m->tm_w1t, m->tm_b1, m->tm_w2t, m->tm_b2, m->pos, t_vec, c->st, m->x, B, D, L, m->extras, m->cfg.normalize_timesteps};
+        DD_HIP(c, launch_time_mlp(ta, s));
+    }
 
     T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
     const int nb = (int)m->blocks.size();
@@ -359,11 +387,15 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         if (!h_ready) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
         h_ready = false;
         {
-            GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, nullptr, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_STORE, s, c->num_cus));
+            GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
+            DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
         }
         DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
-        {
+        if (sizeof(T) == 2 && m->fused_proj) {
+            // x += proj(ao) + b of the patch rows happens inside the fused MLP launch; the extra-token rows (row l of
+            // every image; their MLP runs in the hidden-split workgroups, which read x) get it here
+            DD_HIP(c, proj_extra_rows((const bf16_t*)ao, (const bf16_t*)w.proj_w, w.proj_b, m->x, B, L, m->extras, D, s, c->num_cus));
+        } else {
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
@@ -391,6 +423,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     h_ready = true;
                 }
                 fa.xres = m->x; fa.out = (bf16_t*)copy; fa.ldo = D; fa.partial = m->mlp_partial;
+                if (m->fused_proj) { fa.ao = (const bf16_t*)ao; fa.bproj = w.proj_b; fa.nproj = D / 32; }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
                 if (int rc = mark()) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
@@ -627,8 +660,10 @@ int dd_model_finalize(dd_model* m, int precision) {
     // fused MLP (mlp_fused.hip): bf16 mode only; DD_FUSED_MLP=0 keeps the two-GEMM path (A/B runs)
     const char* env_fused = std::getenv("DD_FUSED_MLP");
     m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(env_fused && env_fused[0] == '0');
+    const char* env_proj = std::getenv("DD_FUSED_PROJ");
+    m->fused_proj = m->fused_mlp && D % 128 == 0 && !(env_proj && env_proj[0] == '0');
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
-    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p; bool skip; };
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b; bool skip; };
     std::vector<BlockOff> boffs;
     auto pack_block = [&](const std::string& p, bool skip) {
         BlockOff o{};
@@ -638,13 +673,16 @@ int dd_model_finalize(dd_model* m, int precision) {
         o.proj_b = put_f32(P(p + "attn.proj.bias").data(), D);
         o.fc1_b = put_f32(P(p + "mlp.fc1.bias").data(), hid); o.fc2_b = put_f32(P(p + "mlp.fc2.bias").data(), D);
         o.qkv_w = put_mat(P(p + "attn.qkv.weight")); o.proj_w = put_mat(P(p + "attn.proj.weight"));
+        if (m->cfg.qkv_bias) o.qkv_b = put_f32(P(p + "attn.qkv.bias").data(), 3 * (size_t)D);
         o.fc1_w = put_mat(P(p + "mlp.fc1.weight")); o.fc2_w = put_mat(P(p + "mlp.fc2.weight"));
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
         if (m->fused_mlp) {
-            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid));
+            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj));
             o.mlp_b1p = put_raw((size_t)hid * 4);
+            const size_t proj_bytes = m->fused_proj ? (size_t)D * D * 2 : 0;      // D/32 blocks of Wproj lead the stream
+            if (m->fused_proj) mlp_fused_pack_proj(D, P(p + "attn.proj.weight").data(), host_f2bf, (unsigned short*)&host[o.mlp_img]);
             mlp_fused_pack(D, hid, P(p + "mlp.fc1.weight").data(), P(p + "mlp.fc1.bias").data(), P(p + "mlp.fc2.weight").data(),
-                           true, host_f2bf, (unsigned short*)&host[o.mlp_img], (float*)&host[o.mlp_b1p]);
+                           true, host_f2bf, (unsigned short*)&host[o.mlp_img + proj_bytes], (float*)&host[o.mlp_b1p]);
         }
         boffs.push_back(o);
     };
@@ -659,6 +697,15 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_wt = put_f32(wt.data(), wt.size()), o_eb = put_f32(P("patch_embed.proj.bias").data(), D);
     const size_t o_pos = put_f32(P("pos_embed").data(), (size_t)L * D);
     const size_t o_lab = m->cfg.num_classes > 0 ? put_f32(P("label_emb.weight").data(), (size_t)m->cfg.num_classes * D) : 0;
+    size_t o_tm[4] = {0, 0, 0, 0};
+    if (m->cfg.mlp_time_embed) {   // transposed: the kernel's threads run over the OUTPUT index
+        const std::vector<float>&w1 = P("time_embed.0.weight"), &w2 = P("time_embed.2.weight");
+        std::vector<float> w1t((size_t)D * 4 * D), w2t((size_t)4 * D * D);
+        for (int j = 0; j < 4 * D; ++j) for (int k = 0; k < D; ++k) w1t[(size_t)k * 4 * D + j] = w1[(size_t)j * D + k];
+        for (int d = 0; d < D; ++d) for (int k = 0; k < 4 * D; ++k) w2t[(size_t)k * D + d] = w2[(size_t)d * 4 * D + k];
+        o_tm[0] = put_f32(w1t.data(), w1t.size()); o_tm[1] = put_f32(P("time_embed.0.bias").data(), 4 * (size_t)D);
+        o_tm[2] = put_f32(w2t.data(), w2t.size()); o_tm[3] = put_f32(P("time_embed.2.bias").data(), D);
+    }
     const size_t o_ng = put_f32(P("norm.weight").data(), D), o_nb = put_f32(P("norm.bias").data(), D);
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
@@ -697,11 +744,12 @@ int dd_model_finalize(dd_model* m, int precision) {
     auto V = [&](size_t off) { return (const void*)(m->warena + off); };
     for (const BlockOff& o : boffs) {
         BlockW w{F(o.ln1_g), F(o.ln1_b), F(o.ln2_g), F(o.ln2_b), F(o.proj_b), F(o.fc1_b), F(o.fc2_b),
-                 o.skip ? F(o.skip_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
+                 o.skip ? F(o.skip_b) : nullptr, m->cfg.qkv_bias ? F(o.qkv_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
                  o.skip ? V(o.skip_w) : nullptr, m->fused_mlp ? (const char*)V(o.mlp_img) : nullptr,
                  m->fused_mlp ? F(o.mlp_b1p) : nullptr};
         m->blocks.push_back(w);
     }
+    if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
     for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv)});
     if (m->ee_type >= 0) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
@@ -982,15 +1030,19 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
 
 int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_host, const float* w1, const float* b1, const float* w2,
                const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in, const float* ln_out,
-               unsigned short* ln_out_host, int iters, void* stream, float* ms_out) {
+               unsigned short* ln_out_host, int iters, void* stream, float* ms_out, const float* ao_host, const float* wproj,
+               const float* bproj) {
+    const bool proj = ao_host && wproj && bproj;
+    if (proj && (!ln_in || D % 128)) return DD_ERR_INVALID;   // the projection rides in the LayerNorm-in kernel only
     if (!c || !x_host || !w1 || !b1 || !w2 || !b2 || !xres_host || M < 1 || iters < 0 || extras < 0 || (extras > 0 && M % (1 + extras))) return DD_ERR_INVALID;
     if (!mlp_fused_supported(D, hidden)) return fail(c, DD_ERR_UNSUPPORTED, "fused MLP: D in {64,128,256,512}, hidden % 64 == 0");
     hipStream_t s = (hipStream_t)stream;
     const size_t Mp = (size_t)round_up(M, 256);
-    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden) / 2, 0);
+    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden, proj) / 2, 0);
     std::vector<float> b1p(hidden), xr(Mp * D, 0.f);
     for (size_t i = 0; i < (size_t)M * D; ++i) { xh[i] = host_f2bf(x_host[i]); xr[i] = xres_host[i]; }
-    mlp_fused_pack(D, hidden, w1, b1, w2, ln_in != nullptr, host_f2bf, img.data(), b1p.data());
+    if (proj) mlp_fused_pack_proj(D, wproj, host_f2bf, img.data());
+    mlp_fused_pack(D, hidden, w1, b1, w2, ln_in != nullptr, host_f2bf, img.data() + (proj ? (size_t)D * D : 0), b1p.data());
     // extras > 0: the M rows are `M / (1 + extras)` images of one patch token each (drives the hidden-split path);
     // extras == 0: one image of M patch tokens (main tiles only)
     MlpFusedArgs a{};
@@ -999,7 +1051,8 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     if (std::getenv("DD_DEV_MLP_EXTRAS_ONLY")) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
     void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
-    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH}) if (p) (void)hipFree(p); };
+    void *dAo = nullptr, *dWp = nullptr, *dBp = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dWp, dBp}) if (p) (void)hipFree(p); };
 #define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
     DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
     DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
@@ -1021,6 +1074,18 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     }
     a.X = (const bf16_t*)dX; a.ldx = D; a.wimg = (const char*)dI; a.b1p = (const float*)dB1; a.b2 = (const float*)dB2;
     a.xres = (float*)dXr; a.out = out_host ? (bf16_t*)dO : nullptr; a.ldo = D; a.partial = (float*)dP;
+    const int dev_L = extras > 0 ? 1 + extras : M, dev_B = extras > 0 ? M / (1 + extras) : 1;
+    if (proj) {   // as run_backbone does it: patch rows inside the launch, extra-token rows by the strided GEMM in front
+        std::vector<unsigned short> ah(Mp * D, 0), wh((size_t)D * D);
+        for (size_t i = 0; i < (size_t)M * D; ++i) ah[i] = host_f2bf(ao_host[i]);
+        for (size_t i = 0; i < wh.size(); ++i) wh[i] = host_f2bf(wproj[i]);
+        DD_TRY(hipMalloc(&dAo, ah.size() * 2)); DD_TRY(hipMalloc(&dWp, wh.size() * 2)); DD_TRY(hipMalloc(&dBp, D * 4));
+        DD_TRY(hipMemcpy(dAo, ah.data(), ah.size() * 2, hipMemcpyHostToDevice));
+        DD_TRY(hipMemcpy(dWp, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+        DD_TRY(hipMemcpy(dBp, bproj, D * 4, hipMemcpyHostToDevice));
+        a.ao = (const bf16_t*)dAo; a.bproj = (const float*)dBp; a.nproj = D / 32;
+        DD_TRY(proj_extra_rows(a.ao, (const bf16_t*)dWp, a.bproj, a.xres, dev_B, dev_L, extras, D, s, c->num_cus));
+    }
     DD_TRY(launch_mlp_fused(a, D, s));
     DD_TRY(hipStreamSynchronize(s));
     DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));

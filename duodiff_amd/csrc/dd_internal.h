@@ -66,6 +66,7 @@ struct GemmArgs {
     T* out;            // [Mp, ldo] or null
     int M, N, K, K1;
     int lda, lda2, ldo;
+    int ldr = 0;       // row stride of xres; 0 = N.  Non-zero (a strided row subset, e.g. the extra-token rows) takes the generic kernel
 };
 
 // num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
@@ -79,6 +80,9 @@ struct MlpFusedArgs {
     int ldx;
     const float* ln_in_g;  // set: the kernel computes LayerNorm(x) * ln_in_g + ln_in_b itself from the residual rows
     const float* ln_in_b;  //      (the W1 image must then be packed with kperm = true)
+    const bf16_t* ao;      // nproj > 0: attention output rows [Mp, D]; the kernel adds ao . Wproj^T + bproj to x first
+    const float* bproj;    //            (main tiles only: the extra-token rows must already hold x1)
+    int nproj;             // D / 32 blocks of Wproj in front of the MLP blocks of wimg, or 0
     const float* ln_out_g; // with ln_out: LayerNorm of the UPDATED rows, written as bf16 [Mp, D] (next block's norm1)
     const float* ln_out_b;
     bf16_t* ln_out;
@@ -96,7 +100,8 @@ struct MlpFusedArgs {
     int tiles_main, tiles_left, groups, cpg;
 };
 bool mlp_fused_supported(int D, int hidden);
-size_t mlp_fused_image_bytes(int D, int hidden);
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj);
+void mlp_fused_pack_proj(int D, const float* wp, unsigned short (*to_bf16)(float), unsigned short* img);
 size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
 void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
@@ -117,6 +122,16 @@ struct EmbedArgs {
     int B, C, S, P, D, L, extras, num_classes, normalize, Mp;
 };
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+
+// time_embed MLP (models/uvit.py:264-272): time token = W2 . SiLU(W1 . sinusoid(t) + b1) + b2 (+ pos_embed), fp32, one
+// workgroup per image; overwrites the time-token row the embed kernel wrote.  w1t [D, 4D], w2t [4D, D]: transposed on the host.
+struct TimeMlpArgs {
+    const float *w1t, *b1, *w2t, *b2, *pos, *t_vec;
+    const StepState* st;
+    float* x_tok;
+    int B, D, L, extras, normalize;
+};
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s);
 
 template <typename T>
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, T* out,

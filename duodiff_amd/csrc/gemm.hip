@@ -138,6 +138,8 @@ gemm_kernel(const GemmArgs<T> a) {
     const int tile_m = wg / n_tiles, tile_n = wg % n_tiles;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int n_limit = a.N - n0;  // rows of W valid in this tile (>= 1)
+    const int m_limit = a.M - m0 < BM ? a.M - m0 : BM;   // rows of A valid in this tile (>= 1); the rest re-read the last one
+    const long long ldr = a.ldr ? a.ldr : a.N;
 
     const int nk = a.K / KT_ELEMS;
     const int nk1 = a.K1 / KT_ELEMS;
@@ -149,8 +151,8 @@ gemm_kernel(const GemmArgs<T> a) {
 
     auto stage = [&](int kt, int buf) {
         char* at = smem + buf * STAGE_BYTES;
-        if (kt < nk1) stage_tile<BM, NW>(A1 + (long long)kt * 128, sa1, at, wave, lane, BM);
-        else stage_tile<BM, NW>(A2 + (long long)(kt - nk1) * 128, sa2, at, wave, lane, BM);
+        if (kt < nk1) stage_tile<BM, NW>(A1 + (long long)kt * 128, sa1, at, wave, lane, m_limit);
+        else stage_tile<BM, NW>(A2 + (long long)(kt - nk1) * 128, sa2, at, wave, lane, m_limit);
         stage_tile<BN, NW>(Wp + (long long)kt * 128, sw, at + A_BYTES, wave, lane, n_limit);
     };
 
@@ -249,7 +251,7 @@ gemm_kernel(const GemmArgs<T> a) {
                         if (EPI != EPI_STORE && a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
                         if (EPI == EPI_BIAS_GELU) v = gelu_erf4<T>(v);
                         if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
-                            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * a.N + col);
+                            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * ldr + col);
                             if (EPI == EPI_BIAS_RESID) v = *xp + v;
                             *xp = v;
                         }
@@ -732,7 +734,7 @@ hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int nu
     } else {
         Part256 p;
         const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
-        if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
+        if (!a.ldr && (a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);   // shapes the 256x256 kernel does not take (small N, tiny M)
     }
 }

@@ -40,6 +40,17 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
+// Same, addressed as (uniform base in SGPRs) + (32-bit lane offset): the base is made opaque so that hipcc keeps the
+// scalar-base form of the instruction instead of folding the lane offset into one 64-bit VGPR pointer per request
+// (16 pairs live across the hot loop otherwise -- the registers the loop does not have).
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ void glds16u(const char* ubase, unsigned voff, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(ubase + voff), (lptr_t)lds_dst, 16, 0, 0);
+}
+
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32
     typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
     typedef float f32v2 __attribute__((ext_vector_type(2)));
@@ -159,11 +170,19 @@ struct MlpCfg {
     static constexpr int FPW = F / 4;          // fragments each of the 4 waves DMAs per block
 };
 
-template <int D, bool LNIN, bool PARTIAL>
+// PROJ (main tiles, LNIN mode): the attention output projection of the block runs in front of the MLP inside the same
+// launch -- x1 = x + ao . Wproj^T + bproj (reference models/uvit.py:206, Attention.proj :166) accumulates on top of x in the
+// output accumulators, norm2 is taken from those registers, the MLP accumulates on top again: x1 never exists in HBM.
+template <int D, bool LNIN, bool PARTIAL, bool PROJ>
 __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
+    static_assert(!PROJ || (LNIN && !PARTIAL && C::NT % 4 == 0), "proj fusion: main tiles of the LayerNorm-in kernel, D % 128 == 0");
     float* b1s = reinterpret_cast<float*>(smem + C::RING);           // [hidden + 32], in accumulator-register order per chunk
-    float* vecs = b1s + (a.nchunks + 1) * 32;                        // 5 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2
+    float* vecs = b1s + (a.nchunks + 1) * 32;                        // 6 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2 | bproj
+    // weight stream: [nproj blocks of Wproj][W1(0) W2(0) W1(1) W2(1) ...]; stream position p lives in ring slot p & 3
+    // (nproj % 4 == 0), so the MLP part keeps "block b in slot b & 3" with or without the projection in front
+    const char* const wproj = a.wimg;
+    const char* const wmlp = a.wimg + (size_t)a.nproj * C::BLK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -193,20 +212,23 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         return (int)(l >> 5) & 1;
     };
 
+    const unsigned dma_voff = (wave * C::FPW) * 1024 + lane * 16;    // this lane's 16 bytes of request j: block + j * 1024 + dma_voff
     // ---- LDS-DMA of one ring block.  Stream position b: chunk b>>1, W1 block if b is even, W2 block if odd.
     auto dma_block = [&](int b, int slot) {
-        const char* src = a.wimg + (size_t)b * C::BLK + (wave * C::FPW) * 1024 + lane * 16;
+        const char* src = uniform_ptr((PROJ ? wproj : wmlp) + (size_t)b * C::BLK);
         char* dst = smem + slot * C::BLK + (wave * C::FPW) * 1024;
 #pragma unroll
-        for (int j = 0; j < C::FPW; ++j) glds16(src + j * 1024, dst + j * 1024);
+        for (int j = 0; j < C::FPW; ++j) glds16u(src + j * 1024, dma_voff, dst + j * 1024);
     };
 
-    // prologue: W1(c0), W2(c0), W1(c0+1) in flight while the X fragments and the bias table are fetched.  c0 is even
-    // (mlp_fused_plan), so block b always lives in ring slot b & 3: W1(c) in slot 0 / 2, W2(c) in slot 1 / 3.
+    // prologue: the first three blocks of the stream (W1(c0), W2(c0), W1(c0+1); with PROJ the first three Wproj blocks) in
+    // flight while the X fragments and the bias table are fetched.  c0 is even (mlp_fused_plan), so block b always lives
+    // in ring slot b & 3: W1(c) in slot 0 / 2, W2(c) in slot 1 / 3.
     dma_block(2 * c0, 0);
     dma_block(2 * c0 + 1, 1);
     dma_block(2 * c0 + 2, 2);
-    {   // slot 3 stands in for "W2 of chunk c0-1": zeros, so that the first iteration's GEMM2 adds nothing
+    if constexpr (!PROJ) {   // slot 3 stands in for "W2 of chunk c0-1": zeros, so that the first iteration's GEMM2 adds nothing
+        // (PROJ: the last Wproj block sits there -- finite, and multiplied by the all-zero activations of "chunk -1")
         f32x4* z = reinterpret_cast<f32x4*>(smem + 3 * C::BLK);
         for (int i = tid; i < C::BLK / 16; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -215,9 +237,9 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(a.b1p)[i];
     {   // per-column vectors -> LDS: the LayerNorm / epilogue arithmetic reads them as broadcast ds_read_b128 (every lane of a
         // half wants the same 16 bytes), not as 300+ vector-memory instructions per lane
-        const float* src[5] = {a.ln_in_g, a.ln_in_b, a.ln_out_g, a.ln_out_b, a.b2};
+        const float* src[6] = {a.ln_in_g, a.ln_in_b, a.ln_out_g, a.ln_out_b, a.b2, a.bproj};
 #pragma unroll
-        for (int v = 0; v < 5; ++v)
+        for (int v = 0; v < 6; ++v)
             if (src[v])
                 for (int i = tid; i < D / 4; i += 256)
                     reinterpret_cast<f32x4*>(vecs + v * D)[i] = reinterpret_cast<const f32x4*>(src[v])[i];
@@ -250,6 +272,15 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         // above the arithmetic (that version spilled); statistics in one pass on register quads (packed fp32 math)
         constexpr int LA = C::NT < 4 ? C::NT : 4;
         f32x4 xq[LA][4];
+        const float* lbp = vecs + 5 * D + 4 * h;     // (PROJ) attn.proj bias
+        if constexpr (PROJ) {
+            // attention output rows of this wave as B fragments (natural k order; they live in the registers the
+            // normalised rows take over afterwards)
+            const bf16_t* ar = a.ao + row_pro * D + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(ar + 16 * ks);
+            __syncthreads();                          // the bias vector is in LDS (and the first Wproj blocks have landed)
+        }
 #pragma unroll
         for (int t = 0; t < LA - 1; ++t)
 #pragma unroll
@@ -263,7 +294,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 q = xq[t % LA][g];
+                f32x4 q = xq[t % LA][g];
+                if constexpr (PROJ) q += *reinterpret_cast<const f32x4*>(lbp + 32 * t + 8 * g);   // x + bproj: the projection accumulates on top
                 s4 += q;
                 q4 += q * q;
 #pragma unroll
@@ -272,6 +304,65 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             acc_pin(Y[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PROJ) {
+            // ---- x1 = x + bproj + ao . Wproj^T : NT phases of F MFMAs, phase t = output columns 32t .. 32t+31 = block t of
+            // the stream.  Before phase t: block t landed (in-order groups, two younger ones may be outstanding) | barrier |
+            // request block t+3 into the slot block t-1 has left.  The last three requests are the MLP's first blocks.
+            const unsigned lds_lo_p = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
+            const unsigned lds_hi_p = lds_lo_p + 65536u;
+            constexpr int PDp = C::F < 8 ? C::F : 8;
+            bf16x8 wp[PDp];
+            GeluPair gr0{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const GeluConst gk0{0.f, 0.f};
+            unsigned none = 0;
+            [&]<int... TI>(std::integer_sequence<int, TI...>) {
+                ([&] {
+                    constexpr int t = TI, slot = t & 3;
+                    if constexpr (t > 0) {
+                        wait_vmcnt<2 * C::FPW>();
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    {   // stream position t + 3: Wproj block, or (t + 3 >= NT) block t + 3 - NT of the MLP part
+                        const char* src = uniform_ptr(a.wimg + (size_t)(t + 3) * C::BLK);
+                        char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
+#pragma unroll
+                        for (int j = 0; j < C::FPW; ++j) glds16u(src + j * 1024, dma_voff, dst + j * 1024);
+                    }
+                    [&]<int... J>(std::integer_sequence<int, J...>) {
+                        ([&] {
+                            constexpr int OFF = slot * C::BLK + J * 1024;
+                            if constexpr (OFF < 65536) lds_frag<OFF>(wp[J], lds_lo_p);
+                            else lds_frag<OFF - 65536>(wp[J], lds_hi_p);
+                        }(), ...);
+                    }(std::make_integer_sequence<int, PDp>{});
+                    [&]<int... FI>(std::integer_sequence<int, FI...>) {
+                        ([&] {
+                            constexpr int f = FI, left = C::F - 1 - f, LG = left < PDp - 1 ? left : PDp - 1;
+                            constexpr bool RD = f + PDp < C::F;
+                            constexpr int LO = RD ? slot * C::BLK + (f + PDp) * 1024 : 0;
+                            constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+                            gap_stmt<1, LG, RD, LOA, -1>(Y[t], wp[f % PDp], xf[f], LO < 65536 ? lds_lo_p : lds_hi_p, 0.f, 0.f, gk0, gr0, none);
+                        }(), ...);
+                    }(std::make_integer_sequence<int, C::F>{});
+                }(), ...);
+            }(std::make_integer_sequence<int, C::NT>{});
+            mfma_drain();
+            // statistics of x1 from the accumulators (one tuple copy per tile)
+            s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            q4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                acc_pin(Y[t]);
+                const f32x16 yt = Y[t];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
+                    s4 += q;
+                    q4 += q * q;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
         sum += __shfl_xor(sum, 32);
         sq += __shfl_xor(sq, 32);
@@ -279,7 +370,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         const float var = sq / (float)D - mean * mean;
         const float rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
         const float shift = -mean * rstd;
-        __syncthreads();   // (vmcnt(0): the prologue blocks have landed; bias table, vectors and zero block are visible)
+        __syncthreads();   // (vmcnt(0): the MLP's first three blocks have landed; bias table, vectors [and zero block] are visible)
         // k-step ks of fc1 = registers 8 (ks & 1) .. + 7 of tile ks >> 1: element j is column
         // 16 ks + 8 (j >> 2) + 4 h + (j & 3) -- the permuted k order the W1 image is packed in (mlp_fused_pack, kperm)
         constexpr int LB = C::NT < 2 ? C::NT : 2;     // (hidden-split tiles) look-ahead of the second read of the row
@@ -393,8 +484,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         constexpr int SLOT_N = PAR ? 3 : 1;        // W2 of chunk c: block 2c+1, the next iteration's first block
         constexpr int NG = 2 * C::F;
         unsigned pw[8];
-        const char* src_e = a.wimg + (size_t)(2 * c + 4) * C::BLK + (wave * C::FPW) * 1024 + lane * 16;   // W1(c+2) -> slot of W1(c)
-        const char* src_m = a.wimg + (size_t)(2 * c + 3) * C::BLK + (wave * C::FPW) * 1024 + lane * 16;   // W2(c+1) -> slot of W2(c-1)
+        const char* src_e = uniform_ptr(wmlp + (size_t)(2 * c + 4) * C::BLK);   // W1(c+2) -> slot of W1(c)
+        const char* src_m = uniform_ptr(wmlp + (size_t)(2 * c + 3) * C::BLK);   // W2(c+1) -> slot of W2(c-1)
         char* dst_e = smem + (PAR ? 2 : 0) * C::BLK + (wave * C::FPW) * 1024;
         char* dst_m = smem + (PAR ? 1 : 3) * C::BLK + (wave * C::FPW) * 1024;
         [&]<int... GI>(std::integer_sequence<int, GI...>) {
@@ -437,8 +528,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 #if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1     // 1 = no DMA in the loop
                 if constexpr (g % DSTEP == DSTEP / 2) {
                     constexpr int j = (g % C::F) / DSTEP;
-                    if constexpr (g < C::F) glds16(src_e + j * 1024, dst_e + j * 1024);
-                    else glds16(src_m + j * 1024, dst_m + j * 1024);
+                    if constexpr (g < C::F) glds16u(src_e + j * 1024, dma_voff, dst_e + j * 1024);
+                    else glds16u(src_m + j * 1024, dma_voff, dst_m + j * 1024);
                 }
 #endif
             }(), ...);
@@ -576,16 +667,16 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 // Either way an optional second LayerNorm (the NEXT block's norm1, models/uvit.py:206) of the updated rows is written
 // as bf16 from the epilogue (a.ln_out), so neither LayerNorm of a block needs a launch or an HBM round trip of x.
 // Workgroups [0, tiles_main) take a main tile each; the rest are the hidden-split workgroups of the extra-token tiles.
-template <int D, bool LNIN>
+template <int D, bool LNIN, bool PROJ>
 __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.tiles_main) {
-        mlp_body<D, LNIN, false>(a, smem, blockIdx.x, 0, a.nchunks, 0);
+        mlp_body<D, LNIN, false, PROJ>(a, smem, blockIdx.x, 0, a.nchunks, 0);
     } else {
         const int e = blockIdx.x - a.tiles_main;
         const int lt = e / a.groups, g = e - lt * a.groups;
         const int c0 = g * a.cpg;
-        mlp_body<D, LNIN, true>(a, smem, lt, c0, c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks, e);
+        mlp_body<D, LNIN, true, false>(a, smem, lt, c0, c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks, e);
     }
 }
 
@@ -635,10 +726,20 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
 
 template <int D>
 hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
-    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 5 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 5 column vectors
+    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 6 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 6 column vectors
     const int grid = a.tiles_main + a.tiles_left * a.groups;
-    if (a.ln_in_g) hipLaunchKernelGGL((mlp_fused_kernel<D, true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((mlp_fused_kernel<D, false>), dim3(grid), dim3(256), lds, s, a);
+    if (a.nproj > 0) {
+        if constexpr (D % 128 == 0) {
+            if (!a.ln_in_g || !a.ao || !a.bproj || a.nproj != D / 32) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((mlp_fused_kernel<D, true, true>), dim3(grid), dim3(256), lds, s, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (a.ln_in_g) {
+        hipLaunchKernelGGL((mlp_fused_kernel<D, true, false>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((mlp_fused_kernel<D, false, false>), dim3(grid), dim3(256), lds, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.tiles_left > 0) {
         hipLaunchKernelGGL(mlp_reduce_kernel<D / 64>, dim3((unsigned)((a.n_extra + 3) / 4)), dim3(256), 0, s, a);
@@ -656,7 +757,20 @@ bool mlp_fused_supported(int D, int hidden) {
 }
 
 // + four blocks: the kernel's DMA runs up to three blocks past the last chunk (branch-free pipeline); never used as data
-size_t mlp_fused_image_bytes(int D, int hidden) { return (size_t)(hidden / 32 + 2) * 2 * (D / 16) * 1024; }
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj) {
+    return ((size_t)(hidden / 32 + 2) * 2 + (with_proj ? D / 32 : 0)) * (D / 16) * 1024;
+}
+
+// Wproj [D, D] (nn.Linear layout) -> D/32 blocks in front of the MLP image: block t = output columns 32t .. 32t+31 as the
+// MFMA A operand, fragment ks = k-step ks in natural k order (its B operand is the attention output as loaded)
+void mlp_fused_pack_proj(int D, const float* wp, unsigned short (*to_bf16)(float), unsigned short* img) {
+    const int F = D / 16;
+    for (int t = 0; t < D / 32; ++t)
+        for (int ks = 0; ks < F; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    img[((size_t)t * F + ks) * 512 + lane * 8 + j] = to_bf16(wp[(size_t)(32 * t + (lane & 31)) * D + 16 * ks + 8 * (lane >> 5) + j]);
+}
 
 // Row plan (see the header): patch rows in 128-row main tiles, extra rows in tiles split `groups` ways along hidden.
 // The split is a function of the hidden size alone -- never of the batch -- so results do not depend on the batch size.
@@ -710,14 +824,18 @@ void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const f
 
 hipError_t init_mlp_fused_kernels() {
     hipError_t e = hipSuccess;
-    const int bias = (kMaxHidden + 32 + 5 * 512) * (int)sizeof(float);
+    const int bias = (kMaxHidden + 32 + 6 * 512) * (int)sizeof(float);
 #define DD_ATTR(DV)                                                                                          \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 MlpCfg<DV>::RING + bias);                                                    \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                MlpCfg<DV>::RING + bias);
+        e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                MlpCfg<DV>::RING + bias);                                                    \
+    if constexpr (DV % 128 == 0)                                                                             \
+        if (e == hipSuccess)                                                                                 \
+            e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    MlpCfg<DV>::RING + bias);
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR
     return e;

@@ -177,6 +177,39 @@ __global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// time_embed MLP of mlp_time_embed=True models (reference models/uvit.py:264-272, applied at :358):
+//   time_token = Linear(4D, D)( SiLU( Linear(D, 4D)( timestep_embedding(t, D) ) ) )
+// One workgroup per image, fp32 throughout; the transposed weights make every read coalesced.  B * 16 D^2 FLOPs per
+// step -- nothing next to a block -- so this stays a plain VALU kernel.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) time_mlp_kernel(const TimeMlpArgs a) {
+    extern __shared__ float tm_lds[];            // [D] sinusoid, then [4D] hidden
+    float* e = tm_lds;
+    float* hmid = tm_lds + a.D;
+    const int b = blockIdx.x, tid = threadIdx.x, D = a.D, H4 = 4 * a.D, halfd = a.D / 2;
+    const float t_raw = a.t_vec ? a.t_vec[b] : a.st->t_model;
+    const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
+    for (int d = tid; d < D; d += 256) {         // same sinusoid as the embed kernels: [cos(t f_i) | sin(t f_i)]
+        const int i = d < halfd ? d : d - halfd;
+        const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
+        e[d] = d < halfd ? cosf(arg) : (d < 2 * halfd ? sinf(arg) : 0.f);
+    }
+    __syncthreads();
+    for (int j = tid; j < H4; j += 256) {
+        float acc = a.b1[j];
+        for (int k = 0; k < D; ++k) acc = fmaf(a.w1t[(long long)k * H4 + j], e[k], acc);
+        hmid[j] = acc / (1.0f + expf(-acc));     // SiLU
+    }
+    __syncthreads();
+    float* row = a.x_tok + ((long long)b * a.L + a.extras - 1) * D;
+    for (int d = tid; d < D; d += 256) {
+        float acc = a.b2[d];
+        for (int k = 0; k < H4; ++k) acc = fmaf(a.w2t[(long long)k * D + d], hmid[k], acc);
+        row[d] = acc + a.pos[(long long)(a.extras - 1) * D + d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5, biased variance, affine): one wave per token row, row held in registers,
 // two-pass statistics.  fp32 in, T out (the GEMM operand type).
 // ------------------------------------------------------------------------------------------
@@ -511,6 +544,11 @@ hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     const long long pad_rows = (long long)a.Mp - (long long)a.B * a.L;
     const int pad_blocks = (int)((pad_rows + kEmbedTok - 1) / kEmbedTok);
     hipLaunchKernelGGL(embed_kernel, dim3(a.B * per_img + pad_blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.B), dim3(256), (size_t)5 * a.D * sizeof(float), s, a);
     return hipGetLastError();
 }
 

@@ -167,7 +167,8 @@ class Model:
     def __init__(self, ctx: Context, mp: ModelParams, max_batch: int):
         self.ctx, self.mp, self.max_batch = ctx, mp, int(max_batch)
         cfg = L.dd_config(mp.img_size, mp.patch_size, mp.in_chans, mp.embed_dim, mp.depth, mp.num_heads,
-                          mp.mlp_ratio, mp.num_classes, int(mp.normalize_timesteps), self.max_batch)
+                          mp.mlp_ratio, mp.num_classes, int(mp.normalize_timesteps), self.max_batch,
+                          int(mp.qkv_bias), int(mp.mlp_time_embed))
         h = C.c_void_p()
         ctx.check(ctx.lib.dd_model_create(ctx.handle, C.byref(cfg), C.byref(h)))
         self.handle = h

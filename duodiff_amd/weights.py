@@ -14,11 +14,13 @@ import torch
 from .config import ModelParams
 
 
-def _block(prefix, D, hidden, skip):
+def _block(prefix, D, hidden, skip, qkv_bias=False):
     s = OrderedDict()
     s[prefix + "norm1.weight"] = (D,)
     s[prefix + "norm1.bias"] = (D,)
     s[prefix + "attn.qkv.weight"] = (3 * D, D)
+    if qkv_bias:                                     # nn.Linear(dim, 3 dim, bias=qkv_bias), models/uvit.py:150
+        s[prefix + "attn.qkv.bias"] = (3 * D,)
     s[prefix + "attn.proj.weight"] = (D, D)
     s[prefix + "attn.proj.bias"] = (D,)
     s[prefix + "norm2.weight"] = (D,)
@@ -41,13 +43,18 @@ def param_shapes(mp: ModelParams) -> "OrderedDict[str, tuple]":
     s["pos_embed"] = (1, mp.seq_len, D)
     s["patch_embed.proj.weight"] = (D, C, P, P)
     s["patch_embed.proj.bias"] = (D,)
+    if mp.mlp_time_embed:                            # Linear(D, 4D) -> SiLU -> Linear(4D, D), models/uvit.py:264-272
+        s["time_embed.0.weight"] = (4 * D, D)
+        s["time_embed.0.bias"] = (4 * D,)
+        s["time_embed.2.weight"] = (D, 4 * D)
+        s["time_embed.2.bias"] = (D,)
     if mp.num_classes > 0:
         s["label_emb.weight"] = (mp.num_classes, D)
     for i in range(mp.depth // 2):
-        s.update(_block(f"in_blocks.{i}.", D, hidden, False))
-    s.update(_block("mid_block.", D, hidden, False))
+        s.update(_block(f"in_blocks.{i}.", D, hidden, False, mp.qkv_bias))
+    s.update(_block("mid_block.", D, hidden, False, mp.qkv_bias))
     for i in range(mp.depth // 2):
-        s.update(_block(f"out_blocks.{i}.", D, hidden, True))
+        s.update(_block(f"out_blocks.{i}.", D, hidden, True, mp.qkv_bias))
     s["norm.weight"] = (D,)
     s["norm.bias"] = (D,)
     s["decoder_pred.weight"] = (mp.patch_dim, D)

@@ -59,6 +59,8 @@ typedef struct dd_config {
     int32_t num_classes;          /* <= 0: unconditional */
     int32_t normalize_timesteps;  /* models/uvit.py:352-353 */
     int32_t max_batch;            /* activation workspace is sized for this many images */
+    int32_t qkv_bias;             /* attn.qkv = nn.Linear(dim, 3 dim, bias=qkv_bias), models/uvit.py:150 (no shipped YAML sets it) */
+    int32_t mlp_time_embed;       /* time_embed = Linear(D,4D) -> SiLU -> Linear(4D,D) on the sinusoid, models/uvit.py:264-272 */
 } dd_config;
 
 /* arithmetic mode of the GEMM / attention operands (accumulation, residual stream,

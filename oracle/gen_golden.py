@@ -95,8 +95,14 @@ def gen_tiny():
         "uncond_raw": dict(TINY, normalize_timesteps=False),
         "cond_raw": dict(TINY, num_classes=10, normalize_timesteps=False),
         "cond_norm_h2": dict(TINY, num_classes=10, embed_dim=128, num_heads=2, depth=5),
+        # the two constructor options no shipped YAML turns on (models/uvit.py:150, 264-272)
+        "timemlp_qkvbias": dict(TINY, mlp_time_embed=True, qkv_bias=True),
+        "cond_timemlp": dict(TINY, num_classes=10, normalize_timesteps=False, mlp_time_embed=True),
     }
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 and sys.argv[1] == "tiny" else None
     for vi, (name, cfg) in enumerate(variants.items()):
+        if only and name not in only:
+            continue
         m, mp = build_ref(cfg, seed=100 + vi)
         g = torch.Generator().manual_seed(200 + vi)
         B = 3
@@ -350,7 +356,7 @@ def gen_rng():
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "vae", "ee", "full"]
+    which = [w for w in sys.argv[1:] if ("gen_" + w) in globals()] or ["schedule", "step", "tiny", "rollout", "scheduler", "rng", "param", "ddim", "vae", "ee", "full"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

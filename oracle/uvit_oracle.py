@@ -131,8 +131,7 @@ class UViTOracle:
         self.num_heads = int(cfg["num_heads"])
         self.num_classes = int(cfg["num_classes"])
         self.normalize_timesteps = bool(cfg["normalize_timesteps"])
-        if cfg.get("mlp_time_embed", False):
-            raise NotImplementedError("mlp_time_embed=True is not used by any shipped config")
+        self.mlp_time_embed = bool(cfg.get("mlp_time_embed", False))
         self.extras = 2 if self.num_classes > 0 else 1
         self.p = {k: np.ascontiguousarray(np.asarray(v, F32)) for k, v in params.items()}
         self.calls = 0
@@ -145,7 +144,12 @@ class UViTOracle:
         if self.normalize_timesteps:                         # uvit.py:352-353
             t = (t / F32(1000)).astype(F32)
         tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"])  # :355
-        time_token = timestep_embedding(t, self.embed_dim)[:, None, :]                   # :358-359
+        time_token = timestep_embedding(t, self.embed_dim)                               # :358
+        if self.mlp_time_embed:                                                          # :264-272 Linear -> SiLU -> Linear
+            hmid = linear(time_token, p["time_embed.0.weight"], p["time_embed.0.bias"])
+            hmid = (hmid / (F32(1) + np.exp(-hmid, dtype=F32))).astype(F32)
+            time_token = linear(hmid, p["time_embed.2.weight"], p["time_embed.2.bias"])
+        time_token = time_token[:, None, :]
         tok = np.concatenate([time_token, tok], axis=1)                                  # :360
         if y is not None:                                                                # :361-364
             tok = np.concatenate([p["label_emb.weight"][np.asarray(y)][:, None, :], tok], axis=1)

@@ -27,7 +27,7 @@ def block(x, p, pre, heads, skip=None):
         x = F.linear(torch.cat([x, skip], dim=-1), p[pre + "skip_linear.weight"], p[pre + "skip_linear.bias"])
     B, L, D = x.shape
     h = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-5)
-    qkv = F.linear(h, p[pre + "attn.qkv.weight"]).reshape(B, L, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+    qkv = F.linear(h, p[pre + "attn.qkv.weight"], p.get(pre + "attn.qkv.bias")).reshape(B, L, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
     a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).permute(0, 2, 1, 3).reshape(B, L, D)
     x = x + F.linear(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"])
     h = F.layer_norm(x, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-5)
@@ -55,7 +55,11 @@ class UViTTorchOracle:
             t = t / 1000
         tok = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=self.P).flatten(2).transpose(1, 2)
         D = tok.shape[-1]
-        tok = torch.cat([timestep_embedding(t, D)[:, None], tok], dim=1)
+        tt = timestep_embedding(t, D)
+        if "time_embed.0.weight" in p:                           # mlp_time_embed=True (models/uvit.py:264-272)
+            tt = F.linear(F.silu(F.linear(tt, p["time_embed.0.weight"], p["time_embed.0.bias"])),
+                          p["time_embed.2.weight"], p["time_embed.2.bias"])
+        tok = torch.cat([tt[:, None], tok], dim=1)
         if y is not None:
             tok = torch.cat([p["label_emb.weight"][torch.as_tensor(y).long()][:, None], tok], dim=1)
         h = tok + p["pos_embed"]

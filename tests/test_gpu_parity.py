@@ -43,7 +43,7 @@ def test_library_loaded_in_tree():
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["uncond_norm", "uncond_raw", "cond_raw", "cond_norm_h2"])
+@pytest.mark.parametrize("name", ["uncond_norm", "uncond_raw", "cond_raw", "cond_norm_h2", "timemlp_qkvbias", "cond_timemlp"])
 def test_forward_tiny_vs_reference(golden, name, precision):
     fx = golden(f"uvit_tiny_{name}.npz")
     cfg = tiny_cfg_from_fixture(fx)

@@ -114,8 +114,12 @@ def test_load_state_dict_surface():
     bad["pos_embed"] = torch.zeros(1, 3, 64)
     with pytest.raises(RuntimeError):
         UViT(**mp.as_dict()).load_state_dict(bad)
-    with pytest.raises(NotImplementedError):
-        UViT(**dict(mp.as_dict(), mlp_time_embed=True))
+    # the two constructor options no shipped YAML uses are part of the schema (models/uvit.py:150, 264-272)
+    mp2 = ModelParams.from_dict(dict(mp.as_dict(), mlp_time_embed=True, qkv_bias=True))
+    keys = set(param_shapes(mp2)) - set(param_shapes(mp))
+    assert {"time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias", "mid_block.attn.qkv.bias"} <= keys
+    with pytest.raises(RuntimeError):                      # a checkpoint without them does not load into such a model
+        UViT(**mp2.as_dict()).load_state_dict(sd)
 
 
 def test_cli_arguments_match_reference_surface():

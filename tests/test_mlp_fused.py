@@ -3,7 +3,8 @@
 bf16-rounded operands, so the tolerance only has to cover the kernel's own arithmetic (bf16 rounding of the hidden
 activation, the GELU polynomial's 2.4e-4, fp32 accumulation order) -- not the bf16 quantisation of the inputs.
 Covers: every supported width, ragged last tiles, the extra-token rows (hidden-split path + reduce kernel), the fused
-LayerNorm prologue / epilogue, and the bf16 copy.  Replaces reference models/uvit.py:86-92, 206-207.
+LayerNorm prologue / epilogue, the bf16 copy, and the attention projection fused in front (x += proj(ao) first, then the
+MLP on the result).  Replaces reference models/uvit.py:86-92, 166, 206-207.
 """
 import ctypes as C
 
@@ -32,10 +33,12 @@ def _reference(h, w1, b1, w2, b2, x):
     return x.astype(np.float64) + _bf16(g.astype(np.float32)).astype(np.float64) @ _bf16(w2).astype(np.float64).T + b2.astype(np.float64)
 
 
-@pytest.mark.parametrize("M,D,extras,ln", [
-    (300, 512, 0, True), (128, 512, 0, False), (700, 512, 1, True), (257 * 3, 512, 2, True),
-    (40, 64, 0, True), (900, 64, 2, True), (700, 128, 1, False), (1500, 256, 0, True)])
-def test_fused_mlp_against_float64_reference(M, D, extras, ln):
+@pytest.mark.parametrize("M,D,extras,ln,proj", [
+    (300, 512, 0, True, False), (128, 512, 0, False, False), (700, 512, 1, True, False), (257 * 3, 512, 2, True, False),
+    (40, 64, 0, True, False), (900, 64, 2, True, False), (700, 128, 1, False, False), (1500, 256, 0, True, False),
+    (300, 512, 0, True, True), (700, 512, 1, True, True), (257 * 3, 512, 2, True, True), (700, 128, 1, True, True),
+    (1500, 256, 0, True, True)])
+def test_fused_mlp_against_float64_reference(M, D, extras, ln, proj):
     from duodiff_amd.engine import Context
     ctx = Context.get()
     hidden = 4 * D
@@ -48,18 +51,25 @@ def test_fused_mlp_against_float64_reference(M, D, extras, ln):
     x = (g.standard_normal((M, D), dtype=np.float32) * 1.5 + 0.3).astype(np.float32)
     ln_in = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
     ln_out = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ao = g.standard_normal((M, D), dtype=np.float32)
+    wp = (g.standard_normal((D, D), dtype=np.float32) * 0.05).astype(np.float32)
+    bp = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x1 = x
+    if proj:                                          # x1 = x + attn.proj(ao): what the MLP then normalises and adds to
+        x1 = (x.astype(np.float64) + _bf16(ao).astype(np.float64) @ _bf16(wp).astype(np.float64).T + bp.astype(np.float64)).astype(np.float32)
     if ln:
-        h = _layernorm(x, ln_in)                      # what the kernel's prologue computes itself from x
-    want = _reference(h, w1, b1, w2, b2, x)
+        h = _layernorm(x1, ln_in)                     # what the kernel's prologue computes itself from x
+    want = _reference(h, w1, b1, w2, b2, x1)
     got, out, hout = x.copy(), np.zeros((M, D), np.uint16), np.zeros((M, D), np.uint16)
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     ms = C.c_float(0)
     ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
                                  P(ln_in) if ln else None, P(ln_out) if ln else None, P(hout) if ln else None, 0,
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms)))
-    scale = float(np.abs(want - x).std())             # size of the MLP's contribution
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
+                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None))
+    scale = float(np.abs(want - x).std())             # size of the block's contribution
     err = np.abs(got - want)
-    print(f"M={M} D={D} extras={extras} ln={ln}: max {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (mlp std {scale:.3f})")
+    print(f"M={M} D={D} extras={extras} ln={ln} proj={proj}: max {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (mlp std {scale:.3f})")
     assert np.isfinite(got).all()
     assert err.max() <= 1.5e-2 * max(scale, 0.1) and np.sqrt((err ** 2).mean()) <= 2e-3 * max(scale, 0.1)
     as_f32 = lambda u: torch.from_numpy(u.view(np.int16)).view(torch.bfloat16).to(torch.float32).numpy()
@@ -87,7 +97,8 @@ def test_fused_mlp_rows_do_not_depend_on_their_neighbours():
         got, hout = x.copy(), np.zeros(x.shape, np.uint16)
         ms = C.c_float(0)
         ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, x.shape[0], D, hidden, extras, P(x), P(w1), P(b1), P(w2), P(b2), P(got), None,
-                                     P(ln), P(ln), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms)))
+                                     P(ln), P(ln), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
+                                     None, None, None))
         return got, hout
 
     big, hbig = run(x_all)

@@ -52,7 +52,7 @@ def test_rng_stream(golden):
     assert np.array_equal(both[: x.size], x.ravel()) and np.array_equal(both[x.size:], z.ravel())
 
 
-@pytest.mark.parametrize("name", ["uncond_norm", "uncond_raw", "cond_raw", "cond_norm_h2"])
+@pytest.mark.parametrize("name", ["uncond_norm", "uncond_raw", "cond_raw", "cond_norm_h2", "timemlp_qkvbias", "cond_timemlp"])
 def test_tiny_per_op(golden, name):
     fx = golden(f"uvit_tiny_{name}.npz")
     cfg = tiny_cfg_from_fixture(fx)

@@ -21,7 +21,7 @@ def main():
     lines = open(out).read().split("\n")
     rc = 0
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
-    assert len(starts) == 2, "expected the LNIN = false / true instantiations"
+    assert len(starts) == 3, "expected the plain, LayerNorm-in and LayerNorm-in + proj instantiations"
     for start in starts:
         end = next(j for j in range(start, len(lines)) if "s_endpgm" in lines[j])
         body = lines[start:end]
