@@ -199,18 +199,18 @@ def main():
         value = images / (dt * 1000.0 / K)
         flop_img = 0.3 * mp_s.flops_per_image() * 1000 + 0.7 * mp_f.flops_per_image() * 1000
         e2e_tflops = value * flop_img / 1e12 / world
-        # Dominant kernel: the fused MLP launch of the full model's blocks (mlp_fused_kernel: norm2 + fc1 + bias + exact-erf
-        # GELU + fc2 + bias + residual + next norm1, plus its small extra-token reduce launch) -- 2/3 of a block's Linear
-        # FLOPs.  Timed live IN CONTEXT: hipEvent pairs on the launch stream around every such launch of 20 eager
-        # full-model steps run right after the timed region (same buffers, cache and clock state as the run).
+        # Dominant kernel: the fused block-tail launch of the full model's blocks (mlp_fused_kernel: attn.proj + residual +
+        # norm2 + fc1 + bias + exact-erf GELU + fc2 + bias + residual + next norm1, plus its small extra-token launches)
+        # -- 3/4 of a block's Linear FLOPs.  Timed live IN CONTEXT: hipEvent pairs on the launch stream around every such
+        # launch of 20 eager full-model steps run right after the timed region (same buffers, cache and clock state).
         with torch.cuda.stream(stream):
             ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, stream=stream)
         M_rows, D_, H_ = B * mp_f.seq_len, mp_f.embed_dim, 4 * mp_f.embed_dim
-        fl = 2.0 * M_rows * D_ * H_ * 2                  # fc1 + fc2
+        fl = 2.0 * M_rows * D_ * H_ * 2 + 2.0 * M_rows * D_ * D_      # fc1 + fc2 + attn.proj
         ach = fl / (ms * 1e-3) / 1e12
-        # algorithmic bytes of one launch: fp32 residual rows read once and written once, bf16 copy for the long skip,
-        # bf16 norm1 output for the next block, the bf16 weights once
-        alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2) + 2 * D_ * H_ * 2
+        # algorithmic bytes of one launch: fp32 residual rows read once and written once, the bf16 attention output read
+        # once, bf16 copy for the long skip, bf16 norm1 output for the next block, the bf16 weights once
+        alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2 + 2) + (2 * D_ * H_ + D_ * D_) * 2
         # HBM bytes / MFMA-busy fraction of that kernel come from the COMMITTED rocprofv3 --pmc profile of this build
         # (profiles/r02/pmc_traffic.json, pmc_sq.json; FETCH_SIZE corrected per profiles/r02/fetch_calibration.txt): they are
         # profile references, not measured in this run -- rocprofv3 cannot run inside this process
@@ -241,7 +241,7 @@ def main():
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "bytes/launch from the committed rocprofv3 --pmc profile profiles/r02/pmc_traffic.json (not measured in this run)",
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "mlp_fused_kernel<512> + mlp_reduce_kernel (norm2 + fc1 + GELU + fc2 + residual + next norm1) M=%d D=%d hidden=%d" % (M_rows, D_, H_),
+                         "kernel": "mlp_fused_kernel<512> (+ proj_rows / mlp_reduce for the extra-token rows): attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d" % (M_rows, D_, H_),
                          "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
                          "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,

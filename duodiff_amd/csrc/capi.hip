@@ -78,6 +78,7 @@ struct dd_model {
     const float *emb_wt = nullptr, *emb_b = nullptr, *pos = nullptr, *label = nullptr;
     const float *tm_w1t = nullptr, *tm_b1 = nullptr, *tm_w2t = nullptr, *tm_b2 = nullptr;   // time_embed MLP (mlp_time_embed)
     const float *norm_g = nullptr, *norm_b = nullptr, *wdec = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
+    const float *wdec_g = nullptr, *dec_c = nullptr;   // head_dec_kernel operands (decoder weight * norm gamma; bias + W . beta) or null
     float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
     std::vector<void*> skips;
     float* dec = nullptr;
@@ -330,18 +331,6 @@ std::vector<std::string> required_names(const dd_model* m) {
 // early-exit taps of one forward (EarlyExitUViT.forward, early_exit.py:290-313): cls [depth, B], outs [depth, B, C, S, S]
 struct EeTaps { float* cls; float* outs; int t; };
 
-// attn.proj + bias + residual of the extra-token rows only (rows l < extras of each image, stride L): the rows the fused
-// kernel's main tiles do not cover.  One small strided GEMM per extra token.
-hipError_t proj_extra_rows(const bf16_t* ao, const bf16_t* wproj, const float* bproj, float* x, int B, int L, int extras, int D,
-                           hipStream_t s, int num_cus) {
-    for (int l = 0; l < extras; ++l) {
-        GemmArgs<bf16_t> g{ao + (size_t)l * D, nullptr, wproj, bproj, x + (size_t)l * D, nullptr, B, D, D, D, L * D, 0, D, L * D};
-        const hipError_t e = launch_gemm<bf16_t>(g, EPI_BIAS_RESID, s, num_cus);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
 template <typename T>
 int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int64_t* y_dev, int B, hipStream_t s,
                  const EeTaps* ee = nullptr) {
@@ -391,11 +380,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
         }
         DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
-        if (sizeof(T) == 2 && m->fused_proj) {
-            // x += proj(ao) + b of the patch rows happens inside the fused MLP launch; the extra-token rows (row l of
-            // every image; their MLP runs in the hidden-split workgroups, which read x) get it here
-            DD_HIP(c, proj_extra_rows((const bf16_t*)ao, (const bf16_t*)w.proj_w, w.proj_b, m->x, B, L, m->extras, D, s, c->num_cus));
-        } else {
+        if (!(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
@@ -425,6 +410,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 fa.xres = m->x; fa.out = (bf16_t*)copy; fa.ldo = D; fa.partial = m->mlp_partial;
                 if (m->fused_proj) { fa.ao = (const bf16_t*)ao; fa.bproj = w.proj_b; fa.nproj = D / 32; }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
+                if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
                 if (int rc = mark()) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
                 if (int rc = mark()) return rc;
@@ -447,6 +433,11 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     // output head (uvit.py:377-378): final LayerNorm in fp32 into scratch (the MLP hidden buffer is
     // free here), then decoder_pred as an exact-fp32 MFMA GEMM in BOTH precision modes, so eps is
     // never rounded to bf16.  dec holds all L tokens per image; the extras are skipped downstream.
+    if (m->wdec_g) {   // fused: rows read once, normalised rows never written
+        HeadDecArgs ha{m->x, m->wdec_g, m->dec_c, m->dec, M, m->pd};
+        DD_HIP(c, launch_head_dec(ha, D, c->num_cus, s));
+        return DD_OK;
+    }
     float* hf = (float*)m->hid;
     DD_HIP(c, launch_layernorm<float>(m->x, m->norm_g, m->norm_b, hf, M, D, s));
     GemmArgs<float> g{hf, nullptr, m->wdec, m->bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
@@ -707,6 +698,23 @@ int dd_model_finalize(dd_model* m, int precision) {
         o_tm[2] = put_f32(w2t.data(), w2t.size()); o_tm[3] = put_f32(P("time_embed.2.bias").data(), D);
     }
     const size_t o_ng = put_f32(P("norm.weight").data(), D), o_nb = put_f32(P("norm.bias").data(), D);
+    // head_dec_kernel operands: the final norm's affine part folded into decoder_pred (dec = Wg . xn + c)
+    const char* env_head = std::getenv("DD_FUSED_HEAD");
+    const bool fused_head = head_dec_supported(D, m->pd) && !(env_head && env_head[0] == '0');
+    size_t o_wg = 0, o_dc = 0;
+    if (fused_head) {
+        const std::vector<float>&wd = P("decoder_pred.weight"), &bd = P("decoder_pred.bias"), &ng = P("norm.weight"), &nbv = P("norm.bias");
+        std::vector<float> wg((size_t)m->pd * D), dc(m->pd);
+        for (int r = 0; r < m->pd; ++r) {
+            double acc = bd[r];
+            for (int k = 0; k < D; ++k) {
+                wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
+                acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
+            }
+            dc[r] = (float)acc;
+        }
+        o_wg = put_f32(wg.data(), wg.size()); o_dc = put_f32(dc.data(), dc.size());
+    }
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
@@ -753,6 +761,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
     for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv)});
     if (m->ee_type >= 0) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
+    if (fused_head) { m->wdec_g = F(o_wg); m->dec_c = F(o_dc); }
     m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdec = F(o_wdec); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
 
     // ---- activation workspace (HBM-resident for the life of the model)
@@ -1051,8 +1060,8 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     if (std::getenv("DD_DEV_MLP_EXTRAS_ONLY")) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
     void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
-    void *dAo = nullptr, *dWp = nullptr, *dBp = nullptr;
-    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dWp, dBp}) if (p) (void)hipFree(p); };
+    void *dAo = nullptr, *dBp = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dBp}) if (p) (void)hipFree(p); };
 #define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
     DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
     DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
@@ -1074,17 +1083,14 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     }
     a.X = (const bf16_t*)dX; a.ldx = D; a.wimg = (const char*)dI; a.b1p = (const float*)dB1; a.b2 = (const float*)dB2;
     a.xres = (float*)dXr; a.out = out_host ? (bf16_t*)dO : nullptr; a.ldo = D; a.partial = (float*)dP;
-    const int dev_L = extras > 0 ? 1 + extras : M, dev_B = extras > 0 ? M / (1 + extras) : 1;
-    if (proj) {   // as run_backbone does it: patch rows inside the launch, extra-token rows by the strided GEMM in front
-        std::vector<unsigned short> ah(Mp * D, 0), wh((size_t)D * D);
+    if (proj) {   // as run_backbone does it: patch rows inside the launch, extra-token rows by the small kernel in front
+        std::vector<unsigned short> ah(Mp * D, 0);
         for (size_t i = 0; i < (size_t)M * D; ++i) ah[i] = host_f2bf(ao_host[i]);
-        for (size_t i = 0; i < wh.size(); ++i) wh[i] = host_f2bf(wproj[i]);
-        DD_TRY(hipMalloc(&dAo, ah.size() * 2)); DD_TRY(hipMalloc(&dWp, wh.size() * 2)); DD_TRY(hipMalloc(&dBp, D * 4));
+        DD_TRY(hipMalloc(&dAo, ah.size() * 2)); DD_TRY(hipMalloc(&dBp, D * 4));
         DD_TRY(hipMemcpy(dAo, ah.data(), ah.size() * 2, hipMemcpyHostToDevice));
-        DD_TRY(hipMemcpy(dWp, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
         DD_TRY(hipMemcpy(dBp, bproj, D * 4, hipMemcpyHostToDevice));
         a.ao = (const bf16_t*)dAo; a.bproj = (const float*)dBp; a.nproj = D / 32;
-        DD_TRY(proj_extra_rows(a.ao, (const bf16_t*)dWp, a.bproj, a.xres, dev_B, dev_L, extras, D, s, c->num_cus));
+        DD_TRY(launch_proj_rows(a, D, s));
     }
     DD_TRY(launch_mlp_fused(a, D, s));
     DD_TRY(hipStreamSynchronize(s));

@@ -66,7 +66,6 @@ struct GemmArgs {
     T* out;            // [Mp, ldo] or null
     int M, N, K, K1;
     int lda, lda2, ldo;
-    int ldr = 0;       // row stride of xres; 0 = N.  Non-zero (a strided row subset, e.g. the extra-token rows) takes the generic kernel
 };
 
 // num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
@@ -106,6 +105,7 @@ size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
 void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
                     unsigned short (*to_bf16)(float), unsigned short* img, float* b1p);
+hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t init_mlp_fused_kernels();
 
@@ -154,6 +154,17 @@ struct FinalArgs {
     int advance;
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
+
+// final LayerNorm + decoder_pred in one launch (rowops.hip); wg = decoder weight * norm gamma [pd, D], c = decoder bias + W . norm beta
+struct HeadDecArgs {
+    const float* x;    // [Mp, D] fp32 residual stream
+    const float* wg;   // [pd, D]
+    const float* c;    // [pd]
+    float* dec;        // [Mp, pd]
+    int M, pd;
+};
+bool head_dec_supported(int D, int pd);
+hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s);
 
 hipError_t launch_ddpm_step(const float* x, const float* eps, const float* z, float* out,
                             StepCoef c, int use_noise, long long n, hipStream_t s);

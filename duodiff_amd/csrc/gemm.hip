@@ -139,7 +139,6 @@ gemm_kernel(const GemmArgs<T> a) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int n_limit = a.N - n0;  // rows of W valid in this tile (>= 1)
     const int m_limit = a.M - m0 < BM ? a.M - m0 : BM;   // rows of A valid in this tile (>= 1); the rest re-read the last one
-    const long long ldr = a.ldr ? a.ldr : a.N;
 
     const int nk = a.K / KT_ELEMS;
     const int nk1 = a.K1 / KT_ELEMS;
@@ -251,7 +250,7 @@ gemm_kernel(const GemmArgs<T> a) {
                         if (EPI != EPI_STORE && a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
                         if (EPI == EPI_BIAS_GELU) v = gelu_erf4<T>(v);
                         if (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET) {
-                            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * ldr + col);
+                            f32x4* xp = reinterpret_cast<f32x4*>(a.xres + (long long)row * a.N + col);
                             if (EPI == EPI_BIAS_RESID) v = *xp + v;
                             *xp = v;
                         }
@@ -734,7 +733,7 @@ hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int nu
     } else {
         Part256 p;
         const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
-        if (!a.ldr && (a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
+        if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);   // shapes the 256x256 kernel does not take (small N, tiny M)
     }
 }

@@ -33,6 +33,8 @@
 namespace dd {
 namespace {
 
+constexpr int kMaxHidden = 4096;   // bias table in LDS next to the 128 KB ring
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -233,16 +235,34 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         for (int i = tid; i < C::BLK / 16; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int i = tid; i < a.nchunks * 8; i += 256)
-        reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(a.b1p)[i];
-    {   // per-column vectors -> LDS: the LayerNorm / epilogue arithmetic reads them as broadcast ds_read_b128 (every lane of a
-        // half wants the same 16 bytes), not as 300+ vector-memory instructions per lane
-        const float* src[6] = {a.ln_in_g, a.ln_in_b, a.ln_out_g, a.ln_out_b, a.b2, a.bproj};
+    {   // bias table and per-column vectors -> LDS (the LayerNorm / epilogue arithmetic reads the vectors as broadcast
+        // ds_read_b128 -- every lane of a half wants the same 16 bytes -- not as 300+ vector-memory instructions per lane).
+        // Every global load is issued before the first LDS write: one memory round trip, not one per vector (hipcc keeps
+        // separate load -> ds_write loops serial, which cost each workgroup ~8 round trips before its first MFMA).
+        constexpr int TB = kMaxHidden / 4 / 256, VQ = 6 * (D / 4), VI = (VQ + 255) / 256;
+        const int nb1 = a.nchunks * 8;
+        f32x4 tb[TB], tv[VI];
+        bool tvok[VI];
 #pragma unroll
-        for (int v = 0; v < 6; ++v)
-            if (src[v])
-                for (int i = tid; i < D / 4; i += 256)
-                    reinterpret_cast<f32x4*>(vecs + v * D)[i] = reinterpret_cast<const f32x4*>(src[v])[i];
+        for (int k = 0; k < TB; ++k) {
+            const int i = tid + 256 * k;
+            tb[k] = reinterpret_cast<const f32x4*>(a.b1p)[i < nb1 ? i : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < VI; ++k) {
+            const int item = tid + 256 * k, v = item / (D / 4), i = item - v * (D / 4);
+            const float* sp = v == 0 ? a.ln_in_g : v == 1 ? a.ln_in_b : v == 2 ? a.ln_out_g : v == 3 ? a.ln_out_b : v == 4 ? a.b2 : a.bproj;
+            tvok[k] = item < VQ && sp != nullptr;
+            tv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tvok[k]) tv[k] = reinterpret_cast<const f32x4*>(sp)[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < TB; ++k)
+            if (tid + 256 * k < nb1) reinterpret_cast<f32x4*>(b1s)[tid + 256 * k] = tb[k];
+#pragma unroll
+        for (int k = 0; k < VI; ++k)
+            if (tvok[k]) reinterpret_cast<f32x4*>(vecs)[tid + 256 * k] = tv[k];
     }
     const float* lg_in = vecs + 4 * h;                 // this lane's column offset inside a quad pair
     const float* lb_in = vecs + D + 4 * h;
@@ -386,6 +406,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         for (int t = 0; t < C::NT; ++t) {
             f32x16 yt;
             if constexpr (!PARTIAL) {
+                acc_pin(Y[t]);                       // (PROJ: the copies made for the statistics die here, not in scratch)
                 yt = Y[t];                           // ONE copy of the tile out of the AGPRs (element-wise access re-reads all 16)
             } else {                                 // hidden-split tiles: the accumulators hold zeros, re-read the row (L1 / L2)
                 if (t + LB - 1 < C::NT) {
@@ -724,6 +745,56 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
     }
 }
 
+// x += ao . Wproj^T + bproj for the extra-token rows (the rows the fused launch's main tiles do not cover; their MLP runs
+// in the hidden-split workgroups, which read the finished x).  Workgroup (t, tile): output columns 32t .. 32t+31 of 128
+// rows, one 32-row group per wave; the Wproj block comes straight from the image's fragment order (one coalesced 16-byte
+// load per lane and k-step), no LDS.  B * extras rows only: a few microseconds in front of the fused launch.
+template <int D>
+__global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
+    using C = MlpCfg<D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int t = blockIdx.x, idx = blockIdx.y * 128 + wave * 32 + (lane & 31);
+    const bool ok = idx < a.n_extra;
+    const int q = ok ? idx : 0, b = q / a.tok_e;
+    const long long row = (long long)b * a.tok_l + (q - b * a.tok_e);
+    const bf16_t* ar = a.ao + row * D + 8 * h;
+    const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wimg + (size_t)t * C::BLK) + lane;
+    float* xr = a.xres + row * D + 32 * t + 4 * h;
+    const float* bp = a.bproj + 32 * t + 4 * h;
+    // every load of the workgroup is issued before the first MFMA (one memory latency, not one per k-step); two
+    // accumulator chains hide the MFMA's own latency
+    bf16x8 wf[C::F], af[C::F];
+#pragma unroll
+    for (int ks = 0; ks < C::F; ++ks) {
+        wf[ks] = wb[ks * 64];
+        af[ks] = *reinterpret_cast<const bf16x8*>(ar + 16 * ks);
+    }
+    f32x4 xq[4], bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        xq[g] = *reinterpret_cast<const f32x4*>(xr + 8 * g);
+        bq[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (hipcc would sink the loads back between the MFMAs to save registers)
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[4 * g + e] = xq[g][e] + bq[g][e];      // same order as the main tiles: (x + b) + products
+            acc1[4 * g + e] = 0.f;
+        }
+#pragma unroll
+    for (int ks = 0; ks < C::F; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[ks], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks + 1], af[ks + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
+    if (!ok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(xr + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+}
+
 template <int D>
 hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 6 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 6 column vectors
@@ -748,7 +819,6 @@ hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     return e;
 }
 
-constexpr int kMaxHidden = 4096;   // bias table in LDS next to the 128 KB ring
 
 }  // namespace
 
@@ -839,6 +909,20 @@ hipError_t init_mlp_fused_kernels() {
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR
     return e;
+}
+
+// extra-token rows of the fused projection (a.ao / a.bproj / a.nproj set as for launch_mlp_fused); no-op without extras
+hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
+    if (a.n_extra <= 0) return hipSuccess;
+    if (a.nproj != D / 32 || !a.ao || !a.bproj) return hipErrorInvalidValue;
+    const dim3 grid(D / 32, (a.n_extra + 127) / 128);
+    switch (D) {
+        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(256), 0, s, a); break;
+        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(256), 0, s, a); break;
+        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s) {

@@ -128,50 +128,76 @@ __global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
     const float t_raw = a.t_vec ? a.t_vec[b] : a.st->t_model;
     const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
     const int halfd = a.D / 2;
-    // pos_embed of row j+1 is requested BEFORE row j is stored: a load queued behind a store of the same
-    // wave would wait for that store (vmcnt retires in order) and serialise the loop on write latency
-    float pos_next[ND];
+    // Tokens in groups of U: the U pos_embed rows of a group are requested together, before any of the group's stores (a
+    // load queued behind a store of the same wave waits for that store -- vmcnt retires in order), so the loop pays one
+    // memory latency per U tokens instead of one per token (what bounded this kernel: ~0.6 us per token and workgroup).
+    constexpr int U = 8;
+    static_assert(TOK % U == 0, "token groups");
+    for (int j0 = 0; j0 < TOK; j0 += U) {
+        if (r0 + j0 >= a.L) break;
+        float posv[U][ND];
 #pragma unroll
-    for (int n = 0; n < ND; ++n) pos_next[n] = r0 < a.L ? a.pos[(long long)r0 * a.D + tid + 256 * n] : 0.f;
-    for (int j = 0; j < TOK; ++j) {
-        const int row = r0 + j;
-        if (row >= a.L) break;
-        float acc[ND], pos_cur[ND];
+        for (int u = 0; u < U; ++u) {
+            const int row = r0 + j0 + u < a.L ? r0 + j0 + u : a.L - 1;
 #pragma unroll
-        for (int n = 0; n < ND; ++n) {
-            pos_cur[n] = pos_next[n];
-            if (row + 1 < a.L && j + 1 < TOK) pos_next[n] = a.pos[(long long)(row + 1) * a.D + tid + 256 * n];
+            for (int n = 0; n < ND; ++n) posv[u][n] = a.pos[(long long)row * a.D + tid + 256 * n];
         }
-        if (row >= a.extras) {
 #pragma unroll
-            for (int n = 0; n < ND; ++n) acc[n] = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u, row = r0 + j;
+            if (row >= a.L) break;
+            float acc[ND];
+            if (row >= a.extras) {
+                if constexpr (ND % 2 == 0) {
+                    // column pairs as 2-vectors: hipcc emits v_pk_fma_f32 (two FMAs per lane and issue slot).  Per element
+                    // the same fmaf chain as below.
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 acc2[ND / 2];
 #pragma unroll
-            for (int k4 = 0; k4 < PD / 4; ++k4) {
-                const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
+                    for (int n = 0; n < ND / 2; ++n) acc2[n] = f32x2{0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                    for (int k4 = 0; k4 < PD / 4; ++k4) {
+                        const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
 #pragma unroll
-                    for (int n = 0; n < ND; ++n) acc[n] = fmaf(w[n][k4 * 4 + e], p[e], acc[n]);
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int n = 0; n < ND / 2; ++n)
+                                acc2[n] = __builtin_elementwise_fma(f32x2{w[2 * n][k4 * 4 + e], w[2 * n + 1][k4 * 4 + e]}, f32x2{p[e], p[e]}, acc2[n]);
+                    }
+#pragma unroll
+                    for (int n = 0; n < ND / 2; ++n) { acc[2 * n] = acc2[n][0]; acc[2 * n + 1] = acc2[n][1]; }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < ND; ++n) acc[n] = 0.f;
+#pragma unroll
+                    for (int k4 = 0; k4 < PD / 4; ++k4) {
+                        const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int n = 0; n < ND; ++n) acc[n] = fmaf(w[n][k4 * 4 + e], p[e], acc[n]);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < ND; ++n) acc[n] += bias[n];
+            } else if (row == a.extras - 1) {
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const int d = tid + 256 * n, i = d < halfd ? d : d - halfd;
+                    const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
+                    acc[n] = d < halfd ? cosf(arg) : sinf(arg);
+                }
+            } else {
+                long long yy = a.y[b];
+                yy = yy < 0 ? 0 : (yy >= a.num_classes ? a.num_classes - 1 : yy);
+#pragma unroll
+                for (int n = 0; n < ND; ++n) acc[n] = a.label_emb[yy * a.D + tid + 256 * n];
             }
-#pragma unroll
-            for (int n = 0; n < ND; ++n) acc[n] += bias[n];
-        } else if (row == a.extras - 1) {
 #pragma unroll
             for (int n = 0; n < ND; ++n) {
-                const int d = tid + 256 * n, i = d < halfd ? d : d - halfd;
-                const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
-                acc[n] = d < halfd ? cosf(arg) : sinf(arg);
+                const int d = tid + 256 * n;
+                a.x_tok[((long long)b * a.L + row) * a.D + d] = acc[n] + posv[u][n];
             }
-        } else {
-            long long yy = a.y[b];
-            yy = yy < 0 ? 0 : (yy >= a.num_classes ? a.num_classes - 1 : yy);
-#pragma unroll
-            for (int n = 0; n < ND; ++n) acc[n] = a.label_emb[yy * a.D + tid + 256 * n];
-        }
-#pragma unroll
-        for (int n = 0; n < ND; ++n) {
-            const int d = tid + 256 * n;
-            a.x_tok[((long long)b * a.L + row) * a.D + d] = acc[n] + pos_cur[n];
         }
     }
 }
@@ -562,7 +588,119 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 template hipError_t launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
 template hipError_t launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 
-hipError_t init_rowops_kernels() { return hipSuccess; }
+// ------------------------------------------------------------------------------------------
+// Output head, first half (reference models/uvit.py:377-378): dec = decoder_pred(norm(x)) in one launch, exact fp32
+// (v_mfma_f32_16x16x4_f32 == an fmaf chain), so eps never sees a bf16 rounding and the normalised rows never exist in HBM.
+// The host folds the affine part of the LayerNorm into the Linear once (finalize):
+//     dec[m] = sum_k (W[m,k] gamma[k]) * ((x[k] - mean) rstd)  +  (b[m] + sum_k W[m,k] beta[k])  =  Wg . xn + c
+// Workgroup = 128 rows, wave = 16 rows held in registers in MFMA B-operand order (lane: row l & 15, k-quad l >> 4),
+// two-pass statistics as layernorm_kernel; Wg is parked in LDS in A-operand order once per workgroup.
+// HBM: the fp32 rows once (the launch's roof), dec once.
+// ------------------------------------------------------------------------------------------
+template <int D, int NT>
+__global__ void __launch_bounds__(512) head_dec_kernel(const HeadDecArgs a) {
+    constexpr int J = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char head_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(head_lds);                 // [J][NT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    // Wg fragments of this wave (L2-resident) -> LDS in A-operand order, all loads in flight at once
+    constexpr int WI = J * NT / 8;
+    static_assert(J * NT % 8 == 0, "one equal share of Wg fragments per wave");
+    {
+        f32x4 wv[WI];
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int item = wave + 8 * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
+            wv[i] = *reinterpret_cast<const f32x4*>(a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q);
+            if (m >= a.pd) wv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wl[(wave + 8 * i) * 64 + lane] = wv[i];
+    }
+    f32x4 c4[NT];    // lane holds dec[row][16 ct + 4 q + i], i < 4 (pd % 4 == 0: a quad is inside or outside)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) c4[ct] = *reinterpret_cast<const f32x4*>(a.c + (16 * ct + 4 * q < a.pd ? 16 * ct + 4 * q : 0));
+    __syncthreads();
+    // 16-row units dealt to the waves of the whole grid, unit u -> wave (u / grid) % 8 of workgroup u % grid: with
+    // M = B (256 + extras) rows the few units beyond one per wave land on different CUs (128-row tiles per workgroup
+    // left one workgroup for a second round of the whole launch).  Nothing below synchronises across waves.
+    const int units = (a.M + 15) / 16, stride = 8 * (int)gridDim.x;
+    for (int u = wave * (int)gridDim.x + (int)blockIdx.x; u < units; u += stride) {
+        const long long row = (long long)u * 16 + n;
+        const bool ok = row < a.M;
+        const f32x4* wlp = wl + lane;
+        asm volatile("" : "+v"(wlp));   // opaque per unit: the LDS fragment reads are loop-invariant and hipcc would hoist all of them (spills)
+        const float* xr = a.x + (ok ? row : (long long)a.M - 1) * D + 4 * q;
+        f32x4 xv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xr + 16 * j);
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < J; ++j) s4 += xv[j];
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)D;
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 d = xv[j] - mean;
+            q4 += d * d;
+        }
+        float sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < J; ++j) xv[j] = (xv[j] - mean) * rstd;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < J; ++j) {      // fully unrolled: xv[] must stay in registers
+            f32x4 w[NT];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) w[ct] = wlp[(j * NT + ct) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][e], xv[j][e], acc[ct], 0, 0, 0);
+        }
+        if (ok) {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const int col = 16 * ct + 4 * q;
+                if (col < a.pd) *reinterpret_cast<f32x4*>(a.dec + row * a.pd + col) = acc[ct] + c4[ct];
+            }
+        }
+    }
+}
+
+bool head_dec_supported(int D, int pd) { return (D == 256 || D == 512) && pd >= 1 && pd <= 64 && pd % 4 == 0; }
+
+hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s) {
+    if (!head_dec_supported(D, a.pd) || a.M < 1) return hipErrorInvalidValue;
+    const int nt = (a.pd + 15) / 16;
+    const int wgs = (a.M + 127) / 128;
+    const dim3 grid((unsigned)(wgs < num_cus ? wgs : num_cus));     // one workgroup per CU (LDS), 16-row units dealt inside
+    const size_t lds = (size_t)(D / 16) * nt * 1024;
+#define DD_HEAD(DV, NV) hipLaunchKernelGGL((head_dec_kernel<DV, NV>), grid, dim3(512), lds, s, a)
+    if (D == 512) { if (nt == 1) DD_HEAD(512, 1); else if (nt == 2) DD_HEAD(512, 2); else if (nt == 3) DD_HEAD(512, 3); else DD_HEAD(512, 4); }
+    else { if (nt == 1) DD_HEAD(256, 1); else if (nt == 2) DD_HEAD(256, 2); else if (nt == 3) DD_HEAD(256, 3); else DD_HEAD(256, 4); }
+#undef DD_HEAD
+    return hipGetLastError();
+}
+
+hipError_t init_rowops_kernels() {
+    hipError_t e = hipSuccess;
+#define DD_HEAD_ATTR(DV, NV)                                                                                       \
+    if (e == hipSuccess)                                                                                           \
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024);
+    DD_HEAD_ATTR(512, 1) DD_HEAD_ATTR(512, 2) DD_HEAD_ATTR(512, 3) DD_HEAD_ATTR(512, 4)
+    DD_HEAD_ATTR(256, 1) DD_HEAD_ATTR(256, 2) DD_HEAD_ATTR(256, 3) DD_HEAD_ATTR(256, 4)
+#undef DD_HEAD_ATTR
+    return e;
+}
 
 namespace {
 // deterministic pseudo-random fill for the GEMM development harness (uniform [-1, 1))

@@ -17,8 +17,8 @@ extern "C" {
  * ln_in [2, D] (gamma, beta) or NULL: the kernel's fused-LayerNorm prologue is used, h = LayerNorm(xres) (h_host ignored);
  * ln_out [2, D] + ln_out_host [M, D] bf16 or NULL: LayerNorm of the updated rows from the epilogue.
  * ao_host [M, D] + wproj [D, D] + bproj [D] or NULL (needs ln_in, D % 128 == 0): the attention projection
- * x += ao . wproj^T + bproj runs in front of the MLP in the same launch (extra-token rows: the strided GEMM the model
- * uses for them). */
+ * x += ao . wproj^T + bproj runs in front of the MLP in the same launch (extra-token rows: the small kernel the model
+ * launches for them). */
 int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
                const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
                const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out,
