@@ -34,6 +34,8 @@ namespace dd {
 namespace {
 
 constexpr int kMaxHidden = 4096;   // bias table in LDS next to the 128 KB ring
+constexpr int kProjRowsLds = 4 * 32 * (1024 + 32);   // proj_rows_kernel: one padded 1 KB strip per LDS-DMA instruction
+constexpr int kGroups = 16;        // hidden-split ways of an extra-token tile (32 measured slower: more slab traffic, same fixed costs)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -290,7 +292,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
         // LA tiles of loads in flight, no more: sched_barrier keeps hipcc from hoisting all 64 loads (256 registers)
         // above the arithmetic (that version spilled); statistics in one pass on register quads (packed fp32 math)
-        constexpr int LA = C::NT < 4 ? C::NT : 4;
+        constexpr int LA = C::NT < 4 ? C::NT : (PARTIAL && C::NT >= 8) ? 8 : 4;   // hidden-split tiles: nothing else is live yet, and the workgroup is pure latency
         f32x4 xq[LA][4];
         const float* lbp = vecs + 5 * D + 4 * h;     // (PROJ) attn.proj bias
         if constexpr (PROJ) {
@@ -319,7 +321,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 s4 += q;
                 q4 += q * q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Y[t][4 * g + e] = PARTIAL ? 0.f : q[e];
+                for (int e = 0; e < 4; ++e) Y[t][4 * g + e] = q[e];
             }
             acc_pin(Y[t]);
             __builtin_amdgcn_sched_barrier(0);
@@ -393,32 +395,10 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         __syncthreads();   // (vmcnt(0): the MLP's first three blocks have landed; bias table, vectors [and zero block] are visible)
         // k-step ks of fc1 = registers 8 (ks & 1) .. + 7 of tile ks >> 1: element j is column
         // 16 ks + 8 (j >> 2) + 4 h + (j & 3) -- the permuted k order the W1 image is packed in (mlp_fused_pack, kperm)
-        constexpr int LB = C::NT < 2 ? C::NT : 2;     // (hidden-split tiles) look-ahead of the second read of the row
-        const float* xr2 = xr;
-        asm volatile("" : "+v"(xr2));                // opaque: hipcc otherwise keeps the 16 tile addresses of the first pass alive (spills)
-        if constexpr (PARTIAL) {
-#pragma unroll
-            for (int t = 0; t < LB - 1; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xq[t][g] = *reinterpret_cast<const f32x4*>(xr2 + 32 * t + 8 * g);
-        }
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
-            f32x16 yt;
-            if constexpr (!PARTIAL) {
-                acc_pin(Y[t]);                       // (PROJ: the copies made for the statistics die here, not in scratch)
-                yt = Y[t];                           // ONE copy of the tile out of the AGPRs (element-wise access re-reads all 16)
-            } else {                                 // hidden-split tiles: the accumulators hold zeros, re-read the row (L1 / L2)
-                if (t + LB - 1 < C::NT) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) xq[(t + LB - 1) % LB][g] = *reinterpret_cast<const f32x4*>(xr2 + 32 * (t + LB - 1) + 8 * g);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) yt[4 * g + e] = xq[t % LB][g][e];
-            }
+            acc_pin(Y[t]);                           // (PROJ: the copies made for the statistics die here, not in scratch)
+            const f32x16 yt = Y[t];                  // ONE copy of the tile out of the AGPRs (element-wise access re-reads all 16)
 #pragma unroll
             for (int kq = 0; kq < 2; ++kq) {
                 const int ks = 2 * t + kq;
@@ -433,6 +413,11 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                     u[2 * gq + 1] = pack2(v[2], v[3]);
                 }
                 xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+            }
+            if constexpr (PARTIAL) {                 // hidden-split tiles accumulate a partial sum: the row only passed through
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Y[t][e] = 0.f;
+                acc_pin(Y[t]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -716,15 +701,32 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
     float acc[VPL], xv[VPL];
 #pragma unroll
     for (int e = 0; e < VPL; ++e) acc[e] = a.b2[col + e];
-    for (int g = 0; g < a.groups; ++g) {
-        const float* pp = a.partial + (((long long)lt * a.groups + g) * 128 + rr) * D + col;
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) acc[e] += pp[e];
-    }
+    // every slab row (and the residual row) is requested before the first add: one memory round trip, not one per group;
+    // the sum still runs over the groups in ascending order
     float* xp = a.xres + row * D + col;
+    float pv[kGroups][VPL];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const float* pp = a.partial + (((long long)lt * a.groups + (g < a.groups ? g : 0)) * 128 + rr) * D + col;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) pv[g][e] = pp[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) xv[e] = xp[e];
+    float gv[VPL], bv[VPL];
+    if (a.ln_out) {
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) { gv[e] = a.ln_out_g[col + e]; bv[e] = a.ln_out_b[col + e]; }
+    }
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g)
+        if (g < a.groups) {
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) acc[e] += pv[g][e];
+        }
     float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < VPL; ++e) { xv[e] = xp[e] + acc[e]; xp[e] = xv[e]; sum += xv[e]; }
+    for (int e = 0; e < VPL; ++e) { xv[e] += acc[e]; xp[e] = xv[e]; sum += xv[e]; }
     if (a.out) {
 #pragma unroll
         for (int e = 0; e < VPL; ++e) a.out[row * a.ldo + col + e] = f2bf(xv[e]);
@@ -741,42 +743,56 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
         const float rstd = 1.0f / sqrtf(q2 / (float)D + 1e-5f);
 #pragma unroll
         for (int e = 0; e < VPL; ++e)
-            a.ln_out[row * D + col + e] = f2bf((xv[e] - mean) * rstd * a.ln_out_g[col + e] + a.ln_out_b[col + e]);
+            a.ln_out[row * D + col + e] = f2bf((xv[e] - mean) * rstd * gv[e] + bv[e]);
     }
 }
 
 // x += ao . Wproj^T + bproj for the extra-token rows (the rows the fused launch's main tiles do not cover; their MLP runs
 // in the hidden-split workgroups, which read the finished x).  Workgroup (t, tile): output columns 32t .. 32t+31 of 128
-// rows, one 32-row group per wave; the Wproj block comes straight from the image's fragment order (one coalesced 16-byte
-// load per lane and k-step), no LDS.  B * extras rows only: a few microseconds in front of the fused launch.
+// rows, one 32-row group per wave.  The kernel is pure latency (B * extras rows), so every load is issued up front and
+// every one is a full-line access: the attention rows -- a sequence length apart in memory -- go whole rows at a time
+// straight into a wave-private LDS strip (LDS-DMA) and are read back as MFMA B fragments; the Wproj block comes straight
+// from the image's fragment order (one coalesced 16-byte load per lane and k-step).
 template <int D>
 __global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
     using C = MlpCfg<D>;
+    constexpr int LPR = D / 8;                 // lanes per attention row (16 bytes each)
+    constexpr int RPI = 64 / LPR;              // rows per LDS-DMA instruction (1 KB, lands contiguously)
+    constexpr int NI = 32 / RPI;               // instructions per wave
+    constexpr int IPITCH = 1024 + 32;          // LDS pitch per instruction: 16-byte reads of consecutive rows spread over the banks
+    extern __shared__ __attribute__((aligned(16))) char strip_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int t = blockIdx.x, idx = blockIdx.y * 128 + wave * 32 + (lane & 31);
+    const int t = blockIdx.x, idx0 = blockIdx.y * 128 + wave * 32;
+    char* strip = strip_lds + wave * (NI * IPITCH);
+    auto row_of = [&](int idx) -> long long {
+        const int q = idx < a.n_extra ? idx : a.n_extra - 1, b = q / a.tok_e;
+        return (long long)b * a.tok_l + (q - b * a.tok_e);
+    };
+#pragma unroll
+    for (int i = 0; i < NI; ++i)               // straight into LDS: no registers held while the rows are in flight
+        glds16(a.ao + row_of(idx0 + i * RPI + lane / LPR) * D + (lane % LPR) * 8, strip + i * IPITCH);
+    __builtin_amdgcn_sched_barrier(0);         // (hipcc puts a vmcnt(0) in front of the first LDS-DMA: nothing may be hoisted above it)
+    const int idx = idx0 + (lane & 31);
     const bool ok = idx < a.n_extra;
-    const int q = ok ? idx : 0, b = q / a.tok_e;
-    const long long row = (long long)b * a.tok_l + (q - b * a.tok_e);
-    const bf16_t* ar = a.ao + row * D + 8 * h;
+    const long long row = row_of(idx);
     const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wimg + (size_t)t * C::BLK) + lane;
     float* xr = a.xres + row * D + 32 * t + 4 * h;
     const float* bp = a.bproj + 32 * t + 4 * h;
-    // every load of the workgroup is issued before the first MFMA (one memory latency, not one per k-step); two
-    // accumulator chains hide the MFMA's own latency
-    bf16x8 wf[C::F], af[C::F];
+    bf16x8 wf[C::F];
 #pragma unroll
-    for (int ks = 0; ks < C::F; ++ks) {
-        wf[ks] = wb[ks * 64];
-        af[ks] = *reinterpret_cast<const bf16x8*>(ar + 16 * ks);
-    }
+    for (int ks = 0; ks < C::F; ++ks) wf[ks] = wb[ks * 64];
     f32x4 xq[4], bq[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         xq[g] = *reinterpret_cast<const f32x4*>(xr + 8 * g);
         bq[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
     }
-    __builtin_amdgcn_sched_barrier(0);      // (hipcc would sink the loads back between the MFMAs to save registers)
-    f32x16 acc, acc1;
+    wait_vmcnt<0>();                        // wave-private strip: this wave's DMA has landed (hipcc does not track LDS-DMA writes)
+    bf16x8 af[C::F];
+    const char* my = strip + ((lane & 31) / RPI) * IPITCH + ((lane & 31) % RPI) * (D * 2) + 16 * h;
+#pragma unroll
+    for (int ks = 0; ks < C::F; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(my + 32 * ks);
+    f32x16 acc, acc1;                       // two accumulator chains hide the MFMA's own latency
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -852,7 +868,7 @@ void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, M
     a.n_extra = B * extras;
     a.tiles_main = (a.n_main + 127) / 128;
     a.tiles_left = (a.n_extra + 127) / 128;
-    int g = nchunks / 2 < 16 ? nchunks / 2 : 16;                     // >= 2 chunks per group (the kernel unrolls by 2)
+    int g = nchunks / 2 < kGroups ? nchunks / 2 : kGroups;                   // >= 2 chunks per group (the kernel unrolls by 2)
     if (g < 1) g = 1;
     a.cpg = ((nchunks + g - 1) / g + 1) & ~1;
     a.groups = (nchunks + a.cpg - 1) / a.cpg;
@@ -908,6 +924,11 @@ hipError_t init_mlp_fused_kernels() {
                                     MlpCfg<DV>::RING + bias);
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR
+#define DD_ATTR_P(DV)                                                                                        \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void*)proj_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds);
+    DD_ATTR_P(128) DD_ATTR_P(256) DD_ATTR_P(512)
+#undef DD_ATTR_P
     return e;
 }
 
@@ -917,9 +938,9 @@ hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
     if (a.nproj != D / 32 || !a.ao || !a.bproj) return hipErrorInvalidValue;
     const dim3 grid(D / 32, (a.n_extra + 127) / 128);
     switch (D) {
-        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(256), 0, s, a); break;
-        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(256), 0, s, a); break;
-        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(256), 0, s, a); break;
+        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(256), kProjRowsLds, s, a); break;
+        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(256), kProjRowsLds, s, a); break;
+        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(256), kProjRowsLds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
