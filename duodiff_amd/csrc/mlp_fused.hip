@@ -328,46 +328,40 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         }
         if constexpr (PROJ) {
             // ---- x1 = x + bproj + ao . Wproj^T : NT phases of F MFMAs, phase t = output columns 32t .. 32t+31 = block t of
-            // the stream.  Before phase t: block t landed (in-order groups, two younger ones may be outstanding) | barrier |
-            // request block t+3 into the slot block t-1 has left.  The last three requests are the MLP's first blocks.
+            // the stream, fed by one fragment queue PDp deep that runs on across the phase boundaries (as in the chunk loop
+            // below).  In the middle of phase t: block t+1 landed (in-order groups, one younger one may be outstanding) |
+            // barrier | request block t+3 into the slot block t-1 has left.  The queue first touches block t+1 after that
+            // point (PDp <= F/2).  The last three requests are the MLP's first blocks.
             const unsigned lds_lo_p = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
             const unsigned lds_hi_p = lds_lo_p + 65536u;
-            constexpr int PDp = C::F < 8 ? C::F : 8;
+            constexpr int PDp = C::F / 2 < 8 ? C::F / 2 : 8;
+            constexpr int NGp = C::NT * C::F;
             bf16x8 wp[PDp];
             GeluPair gr0{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const GeluConst gk0{0.f, 0.f};
             unsigned none = 0;
-            [&]<int... TI>(std::integer_sequence<int, TI...>) {
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                (lds_frag<J * 1024>(wp[J], lds_lo_p), ...);
+            }(std::make_integer_sequence<int, PDp>{});
+            [&]<int... GI>(std::integer_sequence<int, GI...>) {
                 ([&] {
-                    constexpr int t = TI, slot = t & 3;
-                    if constexpr (t > 0) {
-                        wait_vmcnt<2 * C::FPW>();
+                    constexpr int g = GI, t = g / C::F, f = g % C::F;
+                    if constexpr (f == C::F / 2) {
+                        wait_vmcnt<C::FPW>();
                         __builtin_amdgcn_s_barrier();
-                    }
-                    {   // stream position t + 3: Wproj block, or (t + 3 >= NT) block t + 3 - NT of the MLP part
+                        // stream position t + 3: Wproj block, or (t + 3 >= NT) block t + 3 - NT of the MLP part
                         const char* src = uniform_ptr(a.wimg + (size_t)(t + 3) * C::BLK);
                         char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
 #pragma unroll
                         for (int j = 0; j < C::FPW; ++j) glds16u(src + j * 1024, dma_voff, dst + j * 1024);
                     }
-                    [&]<int... J>(std::integer_sequence<int, J...>) {
-                        ([&] {
-                            constexpr int OFF = slot * C::BLK + J * 1024;
-                            if constexpr (OFF < 65536) lds_frag<OFF>(wp[J], lds_lo_p);
-                            else lds_frag<OFF - 65536>(wp[J], lds_hi_p);
-                        }(), ...);
-                    }(std::make_integer_sequence<int, PDp>{});
-                    [&]<int... FI>(std::integer_sequence<int, FI...>) {
-                        ([&] {
-                            constexpr int f = FI, left = C::F - 1 - f, LG = left < PDp - 1 ? left : PDp - 1;
-                            constexpr bool RD = f + PDp < C::F;
-                            constexpr int LO = RD ? slot * C::BLK + (f + PDp) * 1024 : 0;
-                            constexpr int LOA = LO < 65536 ? LO : LO - 65536;
-                            gap_stmt<1, LG, RD, LOA, -1>(Y[t], wp[f % PDp], xf[f], LO < 65536 ? lds_lo_p : lds_hi_p, 0.f, 0.f, gk0, gr0, none);
-                        }(), ...);
-                    }(std::make_integer_sequence<int, C::F>{});
+                    constexpr int gn = g + PDp, left = NGp - 1 - g, LG = left < PDp - 1 ? left : PDp - 1;
+                    constexpr bool RD = gn < NGp;
+                    constexpr int LO = RD ? ((gn / C::F) & 3) * C::BLK + (gn % C::F) * 1024 : 0;
+                    constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+                    gap_stmt<1, LG, RD, LOA, -1>(Y[t], wp[g % PDp], xf[f], LO < 65536 ? lds_lo_p : lds_hi_p, 0.f, 0.f, gk0, gr0, none);
                 }(), ...);
-            }(std::make_integer_sequence<int, C::NT>{});
+            }(std::make_integer_sequence<int, NGp>{});
             mfma_drain();
             // statistics of x1 from the accumulators (one tuple copy per tile)
             s4 = f32x4{0.f, 0.f, 0.f, 0.f};
