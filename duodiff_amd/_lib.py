@@ -11,7 +11,7 @@ DD_ERR_INVALID, DD_ERR_NOT_FOUND, DD_ERR_STATE, DD_ERR_HIP, DD_ERR_NOMEM, DD_ERR
 DD_PREC_BF16, DD_PREC_FP32 = 0, 1
 DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
 DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
-DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 0, 1, 2
+DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, DD_EE_ATTENTION_PROBE = 0, 1, 2, 3
 ABI_VERSION = 2
 
 

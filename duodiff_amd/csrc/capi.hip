@@ -86,6 +86,7 @@ struct dd_model {
     int ee_type = -1, n_probe = 0;
     std::vector<HeadW> heads;             // head i is applied to the input of block i
     const float *probe_w = nullptr, *probe_b = nullptr;   // [n_probe, D], [n_probe]
+    std::vector<AttnProbeW> attn_probes;                  // DD_EE_ATTENTION_PROBE: one per layer
     bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
@@ -190,7 +191,8 @@ int probe_index(const dd_model* m, const std::string& key) {
     };
     int i = 0, t = 0;
     switch (m->ee_type) {
-        case DD_EE_MLP_PER_LAYER: return num(key, i) && i < m->cfg.depth ? i : -1;
+        case DD_EE_MLP_PER_LAYER:
+        case DD_EE_ATTENTION_PROBE: return num(key, i) && i < m->cfg.depth ? i : -1;
         case DD_EE_MLP_PER_TIMESTEP: return num(key, t) && t < 1000 ? t : -1;
         case DD_EE_MLP_PER_LAYER_PER_TIMESTEP: {
             const size_t cpos = key.find(", ");
@@ -203,7 +205,8 @@ int probe_index(const dd_model* m, const std::string& key) {
 }
 std::string probe_key(const dd_model* m, int layer, int t) {
     switch (m->ee_type) {
-        case DD_EE_MLP_PER_LAYER: return std::to_string(layer);
+        case DD_EE_MLP_PER_LAYER:
+        case DD_EE_ATTENTION_PROBE: return std::to_string(layer);
         case DD_EE_MLP_PER_TIMESTEP: return std::to_string(t);
         default: return std::to_string(layer) + ", " + std::to_string(t);
     }
@@ -244,6 +247,19 @@ bool expected_shape(const dd_model* m, const std::string& name, std::vector<int6
     std::string rest;
     bool out_blk = false;
     if (m->ee_type >= 0) {
+        if (name.compare(0, 7, "matrix.") == 0 && m->ee_type == DD_EE_ATTENTION_PROBE) {   // AttentionProbe, early_exit.py:46-58
+            const size_t e = name.find('.', 7);
+            if (e == std::string::npos || probe_index(m, name.substr(7, e - 7)) < 0) return false;
+            const std::string tail = name.substr(e + 1);
+            if (tail == "q") { shp = {1, 1, 1, D}; return true; }
+            if (tail == "weight_kv.weight") { shp = {2 * D, D}; return true; }
+            if (tail == "weight_kv.bias") { shp = {2 * D}; return true; }
+            if (tail == "classification.0.weight") { shp = {D, D}; return true; }
+            if (tail == "classification.0.bias") { shp = {D}; return true; }
+            if (tail == "classification.2.weight") { shp = {1, D}; return true; }
+            if (tail == "classification.2.bias") { shp = {1}; return true; }
+            return false;
+        }
         if (name.compare(0, 7, "matrix.") == 0) {               // matrix.<key>.classifier.0.{weight,bias}
             const size_t e = name.find(".classifier.0.");
             if (e == std::string::npos || probe_index(m, name.substr(7, e - 7)) < 0) return false;
@@ -317,11 +333,19 @@ std::vector<std::string> required_names(const dd_model* m) {
             for (const char* s : {"norm.weight", "norm.bias", "decoder_pred.weight", "decoder_pred.bias",
                                   "final_layer.weight", "final_layer.bias"})
                 v.push_back(head_prefix(m, layer) + s);
-        const int nt = m->ee_type == DD_EE_MLP_PER_LAYER ? 1 : 1000, nl = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : m->cfg.depth;
+        const bool per_layer_only = m->ee_type == DD_EE_MLP_PER_LAYER || m->ee_type == DD_EE_ATTENTION_PROBE;
+        const int nt = per_layer_only ? 1 : 1000, nl = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : m->cfg.depth;
         for (int t = 0; t < nt; ++t)
             for (int layer = 0; layer < nl; ++layer) {
-                v.push_back("matrix." + probe_key(m, layer, t) + ".classifier.0.weight");
-                v.push_back("matrix." + probe_key(m, layer, t) + ".classifier.0.bias");
+                const std::string pre = "matrix." + probe_key(m, layer, t) + ".";
+                if (m->ee_type == DD_EE_ATTENTION_PROBE) {
+                    for (const char* s : {"q", "weight_kv.weight", "weight_kv.bias", "classification.0.weight", "classification.0.bias",
+                                          "classification.2.weight", "classification.2.bias"})
+                        v.push_back(pre + s);
+                } else {
+                    v.push_back(pre + "classifier.0.weight");
+                    v.push_back(pre + "classifier.0.bias");
+                }
             }
     }
     return v;
@@ -364,8 +388,12 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
                          c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
             DD_HIP(c, launch_final(fa, s));
-            const int pi = m->ee_type == DD_EE_MLP_PER_LAYER ? bi : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? ee->t : ee->t * nb + bi;
-            DD_HIP(c, launch_ee_probe(m->x, m->probe_w + (long long)pi * D, m->probe_b + pi, ee->cls + (long long)bi * B, B, L, D, s));
+            if (m->ee_type == DD_EE_ATTENTION_PROBE) {
+                DD_HIP(c, launch_ee_attn_probe(m->x, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, s));
+            } else {
+                const int pi = m->ee_type == DD_EE_MLP_PER_LAYER ? bi : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? ee->t : ee->t * nb + bi;
+                DD_HIP(c, launch_ee_probe(m->x, m->probe_w + (long long)pi * D, m->probe_b + pi, ee->cls + (long long)bi * B, B, L, D, s));
+            }
         }
         if (is_out) {
             const int oi = bi - m->half_depth - 1;
@@ -719,6 +747,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
     struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv; };
+    struct AttnProbeOff { size_t u, wvt, bv, w0t, b0, w2, b2; };
+    std::vector<AttnProbeOff> aoffs;
     std::vector<HeadOff> hoffs;
     size_t o_pw = 0, o_pb = 0;
     if (m->ee_type >= 0) {
@@ -731,6 +761,33 @@ int dd_model_finalize(dd_model* m, int precision) {
             o.bconv = put_f32(P(p + "final_layer.bias").data(), m->cfg.in_chans);
             hoffs.push_back(o);
         }
+        if (m->ee_type == DD_EE_ATTENTION_PROBE) {
+            // AttentionProbe (early_exit.py:40-80), one learned query, one head.  q . (Wk x + bk) = (Wk^T q) . x + const, and the
+            // constant cancels in the softmax; sum_l p_l (Wv x_l + bv) = Wv (sum_l p_l x_l) + bv.  So the probe needs u = Wk^T q /
+            // sqrt(D) (folded here, in double), and Wv / classification.0 transposed for coalesced mat-vecs -- never the [L, 2D] kv.
+            for (int layer = 0; layer < m->cfg.depth; ++layer) {
+                const std::string pre = "matrix." + std::to_string(layer) + ".";
+                const std::vector<float>&q = P(pre + "q"), &wkv = P(pre + "weight_kv.weight"), &bkv = P(pre + "weight_kv.bias"),
+                                        &w0 = P(pre + "classification.0.weight");
+                std::vector<float> u(D), wvt((size_t)D * D), w0t((size_t)D * D);
+                const double scale = 1.0 / std::sqrt((double)D);
+                for (int k = 0; k < D; ++k) {
+                    double acc = 0.0;
+                    for (int j = 0; j < D; ++j) acc += (double)q[j] * (double)wkv[(size_t)j * D + k];
+                    u[k] = (float)(acc * scale);
+                }
+                for (int j = 0; j < D; ++j)
+                    for (int k = 0; k < D; ++k) {
+                        wvt[(size_t)k * D + j] = wkv[(size_t)(D + j) * D + k];
+                        w0t[(size_t)k * D + j] = w0[(size_t)j * D + k];
+                    }
+                AttnProbeOff o{};
+                o.u = put_f32(u.data(), D); o.wvt = put_f32(wvt.data(), wvt.size()); o.bv = put_f32(bkv.data() + D, D);
+                o.w0t = put_f32(w0t.data(), w0t.size()); o.b0 = put_f32(P(pre + "classification.0.bias").data(), D);
+                o.w2 = put_f32(P(pre + "classification.2.weight").data(), D); o.b2 = put_f32(P(pre + "classification.2.bias").data(), 1);
+                aoffs.push_back(o);
+            }
+        } else {
         const int nt = m->ee_type == DD_EE_MLP_PER_LAYER ? 1 : 1000, nl = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : m->cfg.depth;
         m->n_probe = nt * nl;
         std::vector<float> pw((size_t)m->n_probe * D), pb(m->n_probe);
@@ -743,6 +800,7 @@ int dd_model_finalize(dd_model* m, int precision) {
             }
         o_pw = put_f32(pw.data(), pw.size());
         o_pb = put_f32(pb.data(), pb.size());
+        }
     }
     align();
 
@@ -760,7 +818,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
     for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv)});
-    if (m->ee_type >= 0) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
+    if (m->ee_type >= 0 && m->ee_type != DD_EE_ATTENTION_PROBE) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
+    for (const AttnProbeOff& o : aoffs) m->attn_probes.push_back(AttnProbeW{F(o.u), F(o.wvt), F(o.bv), F(o.w0t), F(o.b0), F(o.w2), F(o.b2)});
     if (fused_head) { m->wdec_g = F(o_wg); m->dec_c = F(o_dc); }
     m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdec = F(o_wdec); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
 
@@ -818,8 +877,8 @@ int dd_model_enable_early_exit(dd_model* m, int classifier_type) {
     if (!m) return DD_ERR_INVALID;
     dd_ctx* c = m->ctx;
     if (m->finalized || !m->params.empty()) return fail(c, DD_ERR_STATE, "enable early exit before any parameter is set");
-    if (classifier_type < DD_EE_MLP_PER_LAYER || classifier_type > DD_EE_MLP_PER_LAYER_PER_TIMESTEP)
-        return fail(c, DD_ERR_UNSUPPORTED, "classifier type: only the MLP probes are implemented");
+    if (classifier_type < DD_EE_MLP_PER_LAYER || classifier_type > DD_EE_ATTENTION_PROBE)
+        return fail(c, DD_ERR_UNSUPPORTED, "unknown classifier type");
     m->ee_type = classifier_type;
     return DD_OK;
 }
@@ -831,7 +890,7 @@ int dd_forward_early_exit(dd_ctx* c, dd_model* m, const float* x_dev, float t, c
     if (m->ee_type < 0) return fail(c, DD_ERR_STATE, "model was not created with dd_model_enable_early_exit");
     if (!x_dev || !eps_dev || !classifier_dev || !outputs_dev) return fail(c, DD_ERR_INVALID, "null tensor");
     const int ti = (int)t;                                   // t = int(timesteps[0]) (early_exit.py:271)
-    if (m->ee_type != DD_EE_MLP_PER_LAYER && (ti < 0 || ti > 999)) return fail(c, DD_ERR_NOT_FOUND, "no probe for this timestep (KeyError in the reference)");
+    if (m->ee_type != DD_EE_MLP_PER_LAYER && m->ee_type != DD_EE_ATTENTION_PROBE && (ti < 0 || ti > 999)) return fail(c, DD_ERR_NOT_FOUND, "no probe for this timestep (KeyError in the reference)");
     hipStream_t s = (hipStream_t)stream;
     DD_HIP(c, launch_set_state_float(c->st, t, s));
     const EeTaps ee{classifier_dev, outputs_dev, ti};

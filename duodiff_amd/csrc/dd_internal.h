@@ -181,6 +181,9 @@ template <typename T> hipError_t launch_cast(const float* x, T* out, long long n
 
 hipError_t launch_affine_step(const float* x, const float* m, const float* z, float* out, float a, float b, float c,
                               long long n, hipStream_t s);
+// AttentionProbe operands of one layer (capi.hip finalize folds them): u [D], Wv^T [D, D], bv [D], W0^T [D, D], b0 [D], w2 [D], b2 [1]
+struct AttnProbeW { const float *u, *wvt, *bv, *w0t, *b0, *w2, *b2; };
+hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s);
 hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s);
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
                             float* mo, int* idx, float* err_mean, hipStream_t s);

@@ -525,6 +525,66 @@ __global__ void __launch_bounds__(256) ee_probe_kernel(const float* __restrict__
     if (threadIdx.x == 0) out[b] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)L;
 }
 
+// AttentionProbe (early_exit.py:40-80): one learned query attends over the tokens after the first, then Linear -> SiLU ->
+// Linear(D, 1).  With u = Wk^T q / sqrt(D) folded on the host: p = softmax_l(u . x_l), xbar = sum_l p_l x_l, o = Wv xbar + bv,
+// out = w2 . silu(W0 o + b0) + b2.  One workgroup per image, fp32, fixed-order reductions; LDS: L scores + 3 D-vectors.
+__global__ void __launch_bounds__(256) ee_attn_probe_kernel(const float* __restrict__ x, const AttnProbeW w, float* __restrict__ out,
+                                                            int L, int D) {
+    extern __shared__ float ap_lds[];
+    float* sc = ap_lds;                 // [L] scores -> probabilities (entry 0 unused: the first token is skipped)
+    float* xbar = ap_lds + L;           // [D]
+    float* ov = xbar + D;               // [D]
+    float* hc = ov + D;                 // [D]
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* xb = x + (long long)b * L * D;
+    for (int l = 1 + wave; l < L; l += 4) {
+        const float* xr = xb + (long long)l * D;
+        float d = 0.f;
+        for (int k = lane; k < D; k += 64) d = fmaf(xr[k], w.u[k], d);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) sc[l] = d;
+    }
+    __syncthreads();
+    auto block_reduce = [&](float v, bool is_max) -> float {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const float t = __shfl_xor(v, o); v = is_max ? fmaxf(v, t) : v + t; }
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float mx = -3.0e38f;
+    for (int l = 1 + tid; l < L; l += 256) mx = fmaxf(mx, sc[l]);
+    mx = block_reduce(mx, true);
+    float sum = 0.f;
+    for (int l = 1 + tid; l < L; l += 256) { const float e = expf(sc[l] - mx); sc[l] = e; sum += e; }
+    sum = block_reduce(sum, false);
+    const float inv = 1.0f / sum;
+    for (int k = tid; k < D; k += 256) {
+        float a = 0.f;
+        for (int l = 1; l < L; ++l) a = fmaf(sc[l], xb[(long long)l * D + k], a);
+        xbar[k] = a * inv;
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += 256) {
+        float a = w.bv[j];
+        for (int k = 0; k < D; ++k) a = fmaf(w.wvt[(long long)k * D + j], xbar[k], a);
+        ov[j] = a;
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int j = tid; j < D; j += 256) {
+        float a = w.b0[j];
+        for (int k = 0; k < D; ++k) a = fmaf(w.w0t[(long long)k * D + j], ov[k], a);
+        hc[j] = a / (1.0f + expf(-a));                               // SiLU
+        part = fmaf(w.w2[j], hc[j], part);
+    }
+    part = block_reduce(part, false);
+    if (tid == 0) out[b] = part + w.b2[0];
+}
+
 // eesampler.py:61-67: idx[b] = first layer i in [0, depth] with c[i][b] <= threshold, where c[depth][b] = 0 closes the
 // list (torch.argmax of an all-False column is 0); model_output[b] = (outputs ++ [eps])[idx[b]][b].
 __global__ void ee_select_kernel(const float* __restrict__ outs, const float* __restrict__ eps, const float* __restrict__ cls,
@@ -748,6 +808,10 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
 
 hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s) {
     hipLaunchKernelGGL(ee_probe_kernel, dim3(B), dim3(256), 0, s, x, w, bias, out, L, D);
+    return hipGetLastError();
+}
+hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ee_attn_probe_kernel, dim3(B), dim3(256), (size_t)(L + 3 * D) * sizeof(float), s, x, w, out, L, D);
     return hipGetLastError();
 }
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,

@@ -2,9 +2,9 @@
 
 ``EarlyExitUViT(uvit, classifier_type)`` wraps a :class:`duodiff_amd.uvit.UViT`, loads the reference's state_dict
 (``uvit.*`` + ``matrix.*`` probes + per-layer output heads) and returns ``(eps, classifier_outputs, outputs)`` like the
-reference's forward; the per-layer OutputHead (LayerNorm + Linear + unpatchify + 3x3 conv) and MLPProbe
-(Linear(D,1) + sigmoid + mean over tokens) run in libduodiff.so next to the backbone.  Only the MLP probe types are
-implemented (every shipped deediff_*.yaml uses ``mlp_probe_per_layer``); ``attention_probe`` raises.
+reference's forward; the per-layer OutputHead (LayerNorm + Linear + unpatchify + 3x3 conv) and the uncertainty probe --
+MLPProbe (Linear(D,1) + sigmoid + mean over tokens, three table layouts) or AttentionProbe (one learned query over the
+tokens, then Linear + SiLU + Linear; the reference's default ``classifier_type``) -- run in libduodiff.so next to the backbone.
 """
 from collections import OrderedDict
 
@@ -18,7 +18,7 @@ from .weights import EE_CLASSIFIER_TYPES, ee_param_shapes
 class EarlyExitUViT:
     def __init__(self, uvit: UViT, classifier_type="attention_probe", exit_threshold=0.2):
         if classifier_type not in EE_CLASSIFIER_TYPES:
-            raise NotImplementedError(f"classifier_type {classifier_type!r}: only {EE_CLASSIFIER_TYPES} are implemented")
+            raise ValueError(f"Unknown classifier type: {classifier_type}")
         self.uvit, self.classifier_type, self.exit_threshold = uvit, classifier_type, exit_threshold
         self._state, self._model = None, None
 

@@ -177,9 +177,10 @@ class Model:
 
     def enable_early_exit(self, classifier_type="mlp_probe_per_layer"):
         kinds = {"mlp_probe_per_layer": L.DD_EE_MLP_PER_LAYER, "mlp_probe_per_timestep": L.DD_EE_MLP_PER_TIMESTEP,
-                 "mlp_probe_per_layer_per_timestep": L.DD_EE_MLP_PER_LAYER_PER_TIMESTEP}
+                 "mlp_probe_per_layer_per_timestep": L.DD_EE_MLP_PER_LAYER_PER_TIMESTEP,
+                 "attention_probe": L.DD_EE_ATTENTION_PROBE}
         if classifier_type not in kinds:
-            raise NotImplementedError(f"classifier_type {classifier_type!r}: only the MLP probes are implemented")
+            raise ValueError(f"Unknown classifier type: {classifier_type}")
         self.ctx.check(self.ctx.lib.dd_model_enable_early_exit(self.handle, kinds[classifier_type]))
 
     def forward_early_exit(self, x, t, y=None, t_vec=None, stream=None):

@@ -96,19 +96,18 @@ def synthetic_state_dict(mp: ModelParams, seed: int = 1234, weight_std: float = 
 
 
 # ---- early-exit baseline (reference models/early_exit.py:193-268) ------------------------------
-EE_CLASSIFIER_TYPES = ("mlp_probe_per_layer", "mlp_probe_per_timestep", "mlp_probe_per_layer_per_timestep")
+EE_CLASSIFIER_TYPES = ("attention_probe", "mlp_probe_per_layer", "mlp_probe_per_timestep", "mlp_probe_per_layer_per_timestep")
 
 
 def ee_probe_keys(mp: ModelParams, classifier_type: str):
     """ModuleDict keys of ``EarlyExitUViT.matrix`` (early_exit.py:219-240)."""
-    if classifier_type == "mlp_probe_per_layer":
+    if classifier_type in ("mlp_probe_per_layer", "attention_probe"):
         return [f"{i}" for i in range(mp.depth)]
     if classifier_type == "mlp_probe_per_timestep":
         return [f"{t}" for t in range(1000)]
     if classifier_type == "mlp_probe_per_layer_per_timestep":
         return [f"{i}, {t}" for t in range(1000) for i in range(mp.depth)]
-    raise NotImplementedError(f"classifier_type {classifier_type!r}: only the MLP probes are implemented "
-                              f"(every shipped deediff_*.yaml uses mlp_probe_per_layer)")
+    raise ValueError(f"Unknown classifier type: {classifier_type}")        # early_exit.py:204
 
 
 def ee_head_prefixes(mp: ModelParams):
@@ -123,8 +122,17 @@ def ee_param_shapes(mp: ModelParams, classifier_type: str = "mlp_probe_per_layer
     D, C = mp.embed_dim, mp.in_chans
     s = OrderedDict(("uvit." + k, v) for k, v in param_shapes(mp).items())
     for key in ee_probe_keys(mp, classifier_type):
-        s[f"matrix.{key}.classifier.0.weight"] = (1, D)
-        s[f"matrix.{key}.classifier.0.bias"] = (1,)
+        if classifier_type == "attention_probe":                           # AttentionProbe, early_exit.py:46-58 (num_heads = 1)
+            s[f"matrix.{key}.q"] = (1, 1, 1, D)
+            s[f"matrix.{key}.weight_kv.weight"] = (2 * D, D)
+            s[f"matrix.{key}.weight_kv.bias"] = (2 * D,)
+            s[f"matrix.{key}.classification.0.weight"] = (D, D)
+            s[f"matrix.{key}.classification.0.bias"] = (D,)
+            s[f"matrix.{key}.classification.2.weight"] = (1, D)
+            s[f"matrix.{key}.classification.2.bias"] = (1,)
+        else:
+            s[f"matrix.{key}.classifier.0.weight"] = (1, D)
+            s[f"matrix.{key}.classifier.0.bias"] = (1,)
     for p in ee_head_prefixes(mp):
         s[p + "norm.weight"] = (D,)
         s[p + "norm.bias"] = (D,)
@@ -144,7 +152,11 @@ def synthetic_ee_state_dict(mp: ModelParams, seed: int = 1234, classifier_type: 
     for name, shp in ee_param_shapes(mp, classifier_type).items():
         if name.startswith("uvit."):
             continue
-        if name.startswith("matrix."):
+        if name.startswith("matrix.") and classifier_type == "attention_probe":
+            # q ~ N(0, 4), weights ~ N(0, (2/sqrt(D))^2): scores spread enough for a non-uniform softmax, outputs O(1)
+            t = 2.0 * torch.randn(shp, generator=g) if name.endswith(".q") else \
+                (2.0 / D ** 0.5) * torch.randn(shp, generator=g) if name.endswith("weight") else 0.3 * torch.randn(shp, generator=g)
+        elif name.startswith("matrix."):
             t = (4.0 / D ** 0.5) * torch.randn(shp, generator=g) if name.endswith("weight") else torch.randn(shp, generator=g)
         elif name.endswith("norm.weight"):
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)

@@ -113,15 +113,17 @@ int dd_forward(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const floa
                const int64_t* y_dev, float* eps_dev, int B, void* stream);
 
 /* ---- early-exit baseline: EarlyExitUViT (models/early_exit.py:193-324) + eesampler.py ---- */
-/* Which uncertainty probe the model carries (early_exit.py:194-204).  attention_probe is not implemented
- * (no shipped config uses it). */
-enum { DD_EE_MLP_PER_LAYER = 0, DD_EE_MLP_PER_TIMESTEP = 1, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 2 };
+/* Which uncertainty probe the model carries (early_exit.py:194-204): the three MLPProbe tables (:31-37) or the
+ * per-layer AttentionProbe (:40-80, the reference's default classifier_type). */
+enum { DD_EE_MLP_PER_LAYER = 0, DD_EE_MLP_PER_TIMESTEP = 1, DD_EE_MLP_PER_LAYER_PER_TIMESTEP = 2, DD_EE_ATTENTION_PROBE = 3 };
 /* Call right after dd_model_create.  dd_model_set_param then also takes the EarlyExitUViT state_dict names
- * (U-ViT names WITHOUT the "uvit." prefix, plus "matrix.<key>.classifier.0.{weight,bias}",
+ * (U-ViT names WITHOUT the "uvit." prefix, plus "matrix.<key>.classifier.0.{weight,bias}" -- for the attention probe
+ * "matrix.<i>.{q, weight_kv.weight, weight_kv.bias, classification.0.weight, classification.0.bias,
+ * classification.2.weight, classification.2.bias}" --,
  * "in_blocks_heads.<i>.*", "mid_block_head.*", "out_blocks_heads.<i>.*") and finalize requires all of them. */
 int dd_model_enable_early_exit(dd_model* m, int classifier_type);
 /* (eps, classifier_outputs, outputs) = EarlyExitUViT.forward(x, timesteps, y) (early_exit.py:270-320).
- * t = int(timesteps[0]) selects the probes; t_dev as in dd_forward.  classifier_dev [depth, B] fp32: the MLPProbe
+ * t = int(timesteps[0]) selects the probes; t_dev as in dd_forward.  classifier_dev [depth, B] fp32: the probe
  * of the input of every block; outputs_dev [depth, B, C, S, S] fp32: the OutputHead of the same inputs. */
 int dd_forward_early_exit(dd_ctx* ctx, dd_model* m, const float* x_dev, float t, const float* t_dev,
                           const int64_t* y_dev, float* eps_dev, float* classifier_dev, float* outputs_dev,

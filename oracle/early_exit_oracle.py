@@ -1,6 +1,6 @@
 """Oracle (test infrastructure): the early-exit baseline (DeeDiff / AdaDiff), numpy fp32.
 
-Follows reference models/early_exit.py: OutputHead.forward :22-28, MLPProbe.forward :36-37,
+Follows reference models/early_exit.py: OutputHead.forward :22-28, MLPProbe.forward :36-37, AttentionProbe :40-80,
 EarlyExitUViT.get_classifer :194-204 and .forward :270-320; and eesampler.py get_samples :40-89 (the "simulated"
 early exit: every layer runs, the per-sample output is gathered from the first layer whose predicted error is
 <= threshold).  Pinned by tests/golden/ee_*.npz generated from the reference's own modules.
@@ -31,11 +31,28 @@ class EarlyExitOracle:
         self.normalize_timesteps = bool(cfg.get("normalize_timesteps", True))
 
     def _probe_key(self, t, i):                                   # early_exit.py:194-204
-        return {"mlp_probe_per_layer": f"{i}", "mlp_probe_per_timestep": f"{t}",
+        return {"mlp_probe_per_layer": f"{i}", "mlp_probe_per_timestep": f"{t}", "attention_probe": f"{i}",
                 "mlp_probe_per_layer_per_timestep": f"{i}, {t}"}[self.classifier_type]
+
+    def _attention_probe(self, h, k):                             # :60-80, num_heads = 1
+        p, D = self.p, self.embed_dim
+        xs = h[:, 1:, :]                                          # :72 "ignore time vector": the FIRST token, whatever it is
+        kv = linear(xs, p[f"matrix.{k}.weight_kv.weight"], p[f"matrix.{k}.weight_kv.bias"])
+        kk, vv = kv[..., :D], kv[..., D:]                         # "b l (k h hd) -> k b h l hd", k = 2, h = 1
+        q = p[f"matrix.{k}.q"].reshape(D)
+        s = (kk @ q).astype(F32) * F32(1.0 / np.sqrt(D))          # F.scaled_dot_product_attention: scale 1/sqrt(head_dim)
+        s = s - s.max(axis=1, keepdims=True)
+        e = np.exp(s, dtype=F32)
+        pr = (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
+        o = np.einsum("bl,bld->bd", pr, vv).astype(F32)
+        z = linear(o, p[f"matrix.{k}.classification.0.weight"], p[f"matrix.{k}.classification.0.bias"])
+        z = (z * _sigmoid(z)).astype(F32)                         # SiLU
+        return linear(z, p[f"matrix.{k}.classification.2.weight"], p[f"matrix.{k}.classification.2.bias"])[:, 0]
 
     def _probe(self, h, t, i):                                    # :36-37: sigmoid(Linear(D,1)).mean over ALL tokens
         k = self._probe_key(t, i)
+        if self.classifier_type == "attention_probe":
+            return self._attention_probe(h, k)
         v = linear(h, self.p[f"matrix.{k}.classifier.0.weight"], self.p[f"matrix.{k}.classifier.0.bias"])
         return _sigmoid(v)[..., 0].mean(axis=1, dtype=F32)
 

@@ -297,7 +297,7 @@ def gen_vae():
 
 
 def gen_ee():
-    """Early-exit baseline: EarlyExitUViT.forward (models/early_exit.py:270-320) for the three MLP probe types, and the
+    """Early-exit baseline: EarlyExitUViT.forward (models/early_exit.py:270-320) for the three MLP probe types and the attention probe, and the
     eesampler.get_samples rollout (eesampler.py:40-89), tiny model, reference code on CPU."""
     from duodiff_amd.weights import synthetic_ee_state_dict
     with contextlib.redirect_stdout(io.StringIO()):
@@ -315,13 +315,16 @@ def gen_ee():
     g = torch.Generator().manual_seed(808)
     cases = [("layer", dict(TINY), "mlp_probe_per_layer", 41, 640.0),
              ("timestep", dict(TINY), "mlp_probe_per_timestep", 42, 17.0),
-             ("layer_timestep_cond", dict(TINY, num_classes=10), "mlp_probe_per_layer_per_timestep", 43, 999.0)]
+             ("layer_timestep_cond", dict(TINY, num_classes=10), "mlp_probe_per_layer_per_timestep", 43, 999.0),
+             ("attention", dict(TINY), "attention_probe", 44, 321.0),
+             ("attention_cond", dict(TINY, num_classes=10), "attention_probe", 45, 77.0)]
     for tag, cfg, ctype, seed, t in cases:
         m, mp = build(cfg, seed, ctype)
         x = torch.randn(3, 3, 8, 8, generator=g)
         y = torch.tensor([1, 9, 4]) if cfg["num_classes"] > 0 else None
         with torch.no_grad():
             eps, cls, outs = m(x, t * torch.ones(3), y)
+        cls = [c.reshape(3) for c in cls]
         out.update({f"{tag}_x": x.numpy(), f"{tag}_t": np.array(t, np.float32), f"{tag}_seed": np.array(seed),
                     f"{tag}_eps": eps.numpy(), f"{tag}_cls": torch.stack(cls).numpy(), f"{tag}_outs": torch.stack(outs).numpy()})
         if y is not None:
