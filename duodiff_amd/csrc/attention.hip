@@ -26,14 +26,24 @@ constexpr int kLP = kMaxKeyTiles * 32;   // padded key count held in LDS
 constexpr int kHD = 64;
 constexpr int kPartBytes = 4 * 2 * 66 * 4;   // split last query chunk: [4 waves][2 queries][64 d, max, sum] fp32
 
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 template <typename T> struct AttnLayout;
 template <> struct AttnLayout<bf16_t> {
     static constexpr int kRowK = 128 + 16;        // K row: 64 bf16 + 16 B pad  (36 dwords: b128 reads conflict-free)
-    static constexpr int kRowV = kLP * 2 + 8;     // V^T row: 288 bf16 + 8 B pad (146 dwords = 2 mod 64: b64 reads conflict-free)
+    // V stays ROW-major ([key][64 d], 128-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ 2 (r & 3)): staged with
+    // plain 16-byte LDS writes, and read as the V^T MFMA operand with the transposing ds_read_b64_tr_b16 (a block of 4 keys x
+    // 16 d per 16 lanes; the XOR puts the four rows of a block into the four bank quarters: conflict-free).  The first
+    // version wrote V transposed with 4-byte scattered LDS writes -- 12 of the kernel's 47 us.
+    static constexpr int kRowV = 128;
+    static constexpr int kVBytes = kLP * kRowV;
 };
 template <> struct AttnLayout<float> {
     static constexpr int kRowK = 256 + 16;        // 68 dwords = 4 mod 64
-    static constexpr int kRowV = kLP * 4 + 16;    // 292 dwords = 4 mod 64
+    static constexpr int kRowV = kLP * 4 + 16;    // V^T row (fp32 path keeps the transposed image): 292 dwords = 4 mod 64
+    static constexpr int kVBytes = kHD * kRowV;
 };
 
 // NKT > 0: the number of 32-key tiles is a compile-time constant (9 for L = 257/258: every shipped
@@ -45,7 +55,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     using Lay = AttnLayout<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                   // [kLP][kRowK]
-    char* Vt = smem + kLP * Lay::kRowK;                // [64][kRowV]
+    char* Vt = smem + kLP * Lay::kRowK;                // bf16: V [kLP][128 B] swizzled; fp32: V^T [64][kRowV]
 
     const int b = blockIdx.x / H, hh = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,10 +83,14 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
     // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
     if constexpr (sizeof(T) == 2) {
-        // two keys per item, so V^T goes in as dwords {V[2k][d], V[2k+1][d]} instead of 2-byte writes.
+        // two keys per item (K and V rows go in as 16-byte chunks).
         // All loads of the (at most 5) items of a thread are issued BEFORE the first LDS write: written as a plain loop the
         // compiler keeps load -> wait -> write per iteration, i.e. five serial HBM round trips per workgroup.
+#if defined(DD_ATTN_ABLATE) && (DD_ATTN_ABLATE == 2 || DD_ATTN_ABLATE >= 5)     // development builds only (tools/build_variant.py): 2, 5.. = no staging
+        const int items = 0;
+#else
         const int items = nkt * 16 * CPR;
+#endif
         constexpr int ITER = (kMaxKeyTiles * 16 * CPR + 255) / 256;
         f32x4 k0[ITER], k1[ITER], v0[ITER], v1[ITER];
 #pragma unroll
@@ -84,6 +98,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             const int idx = tid + it * 256;
             const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
             k0[it] = k1[it] = v0[it] = v1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(DD_ATTN_ABLATE) || DD_ATTN_ABLATE != 4     // 4 = LDS writes of zeros, no loads
             if (idx < items && key < L) {
                 k0[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
                 v0[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
@@ -92,21 +107,23 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                 k1[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
                 v1[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
             }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * 256;
             const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
+#if defined(DD_ATTN_ABLATE) && DD_ATTN_ABLATE == 3     // 3 = loads only: one LDS write per item keeps them alive
+            if (idx < items) *reinterpret_cast<f32x4*>(Ks + tid * 16) = k0[it] + k1[it] + v0[it] + v1[it];
+            if (false) {
+#else
             if (idx < items) {
+#endif
                 *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0[it];
                 *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1[it];
-                const bf16x8 a = __builtin_bit_cast(bf16x8, v0[it]), b = __builtin_bit_cast(bf16x8, v1[it]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned pair = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
-                    *reinterpret_cast<unsigned*>(Vt + (ch * 8 + e) * Lay::kRowV + key * 2) = pair;
-                }
+                *reinterpret_cast<f32x4*>(Vt + key * Lay::kRowV + ((ch ^ (2 * (key & 3))) << 4)) = v0[it];
+                *reinterpret_cast<f32x4*>(Vt + (key + 1) * Lay::kRowV + ((ch ^ (2 * ((key + 1) & 3))) << 4)) = v1[it];
             }
         }
     } else {
@@ -127,17 +144,19 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     }
 
     __syncthreads();
+#if defined(DD_ATTN_ABLATE) && (DD_ATTN_ABLATE == 1 || DD_ATTN_ABLATE >= 3)     // 1 = staging only (3, 4: parts of it)
+    if (Ks[tid] != 77) return;
+#endif
 
     // One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
     // O^T (two 32(d) x 32(q) tiles), the chunk's running max and the sum of exponentials.
     auto attend = [&](auto nt_tag, auto&& tile, const f32x4 (&qcur)[NQF], f32x16 (&o)[2], float& mx, float& sum) {
         constexpr int NT = decltype(nt_tag)::value;
         // ---- S^T = K . Q^T, tiles of 32 keys x 32 queries
+        // (accumulators start from a literal zero C operand in the first MFMA of a tile: a separate zero-fill is 16 v_mov per
+        // tile -- 176 issue slots per chunk in a kernel that is bound by vector issue, not by the matrix pipe)
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 s[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[k][e] = 0.f;
 
         if constexpr (sizeof(T) == 2) {
             bf16x8 qf[4];
@@ -159,9 +178,12 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                 if (tn >= 0) { if (k & 1) load_k(tn, kfa); else load_k(tn, kfb); }
                 __builtin_amdgcn_sched_barrier(0);  // the look-ahead reads go out BEFORE this tile's MFMAs
                 if (t >= 0) {
+                    s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[0] : kfa[0], qf[0], zero16, 0, 0, 0);
 #pragma unroll
-                    for (int st = 0; st < 4; ++st)
+                    for (int st = 1; st < 4; ++st)
                         s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[st] : kfa[st], qf[st], s[k], 0, 0, 0);
+                } else {
+                    s[k] = zero16;
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one tile of look-ahead, no further hoisting (it would spill)
             }
@@ -170,6 +192,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int t = tile(k);
+                s[k] = zero16;
                 if (t >= 0) {
                     const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
 #pragma unroll
@@ -212,8 +235,12 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float p;
+#if defined(DD_ATTN_ABLATE) && DD_ATTN_ABLATE == 5     // 5 = no exp (a multiply in its place)
+                    p = fmaf(s[k][e], kScaleLog2e, -mxs) * 0.001f;
+#else
                     if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[k][e], kScaleLog2e, -mxs));
                     else p = expf((s[k][e] - mx) * 0.125f);
+#endif
                     s[k][e] = p;
                     sum += p;
                 }
@@ -222,23 +249,28 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         sum += __shfl_xor(sum, 32);
 
         // ---- O^T = V^T . P^T : two 32(d) x 32(q) tiles
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+        o[0] = zero16;
+        o[1] = zero16;
 
         if constexpr (sizeof(T) == 2) {
             // V^T fragments double-buffered like the K fragments: [st][dt], keys t*32 + 16*st + 4*half + {0..3, 8..11}
             typedef __attribute__((ext_vector_type(4))) short s4;
             struct VF { s4 lo[2][2], hi[2][2]; };
+            // lane = (half, dhalf, q, p): its 16-lane group reads the block keys 16 st + 4 half + {0..3} (hi: + 8) x d 16 dhalf .. + 15
+            // of d-tile dt and supplies the address of row q, 8-byte piece p; lane i of the group receives column i, i.e. this
+            // lane ends up with V[those 4 keys][dt * 32 + (lane & 31)] -- the V^T fragment the MFMA wants.
+            const int tq = (lane >> 2) & 3, tp = lane & 3, dhalf = (lane >> 4) & 1;
+            const char* vb0 = Vt + (4 * half + tq) * Lay::kRowV + 8 * (tp & 1);
+            const char* vbd[2] = {vb0 + (((2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4), vb0 + (((4 + 2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4)};
+            typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
             auto load_v = [&](int t, VF& f) {
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 16 * st + 4 * half) * 2;
-                        f.lo[st][dt] = *reinterpret_cast<const s4*>(vr);        // keys +0..3
-                        f.hi[st][dt] = *reinterpret_cast<const s4*>(vr + 16);   // keys +8..11
+                        const char* vr = vbd[dt] + (t * 32 + 16 * st) * Lay::kRowV;
+                        f.lo[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr));
+                        f.hi[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr + 8 * Lay::kRowV));
                     }
             };
             VF va, vb;
@@ -332,7 +364,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
     if constexpr (SPLIT_LAST) {
         // wave w: key tiles w, w+4 and (wave 3) the 9th tile, which holds the keys of the extra tokens themselves
-        float* part = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + kHD * Lay::kRowV);   // [4 waves][2 queries][64 d + max + sum]
+        float* part = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + Lay::kVBytes);   // [4 waves][2 queries][64 d + max + sum]
         const int rem = L - 256;                                                               // 1 or 2 valid queries
         f32x16 o[2];
         float mx, sum;
@@ -373,15 +405,15 @@ template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s) {
     if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
     using Lay = AttnLayout<T>;
-    const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)kHD * Lay::kRowV + kPartBytes;
+    const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)Lay::kVBytes + kPartBytes;
     if ((L + 31) / 32 == 9) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     return hipGetLastError();
 }
 
 hipError_t init_attention_kernels() {
-    const int lb = kLP * AttnLayout<bf16_t>::kRowK + kHD * AttnLayout<bf16_t>::kRowV + kPartBytes;
-    const int lf = kLP * AttnLayout<float>::kRowK + kHD * AttnLayout<float>::kRowV + kPartBytes;
+    const int lb = kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kPartBytes;
+    const int lf = kLP * AttnLayout<float>::kRowK + AttnLayout<float>::kVBytes + kPartBytes;
     hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attention_kernel<float, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lf);
