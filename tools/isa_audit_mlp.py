@@ -23,7 +23,7 @@ def main():
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
     assert len(starts) == 3, "expected the plain, LayerNorm-in and LayerNorm-in + proj instantiations"
     for start in starts:
-        end = next(j for j in range(start, len(lines)) if "s_endpgm" in lines[j])
+        end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))   # (a kernel may have several s_endpgm)
         body = lines[start:end]
         loops = []
         for head in (i for i, l in enumerate(body) if "Loop Header" in l):
