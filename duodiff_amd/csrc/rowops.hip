@@ -3,6 +3,8 @@
 // All arithmetic here is fp32 in both precision modes.
 #include "dd_internal.h"
 
+#include <cstdlib>
+
 namespace dd {
 namespace {
 
@@ -199,6 +201,125 @@ __global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
                 a.x_tok[((long long)b * a.L + row) * a.D + d] = acc[n] + posv[u][n];
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Patch embedding on the matrix pipe (exact fp32: v_mfma_f32_16x16x4_f32 == an fmaf chain in k order), for image grids
+// of 16 patches per row (every shipped config).  The VALU kernel above is bound by its PD * D FMAs per token (0.8 G per
+// launch = 26 us of pure VALU issue); the f32 MFMA does the same arithmetic at twice that rate and leaves the vector
+// pipe to the address math, so the launch approaches its 67 MB of output writes.
+//   workgroup = 8 waves = 8 patch rows of an image (2 workgroups per image: one per CU at B = 128, a single round);
+//   wave      = one patch row = 16 tokens as the MFMA N dimension: B operand = the 16 patches (lane (n, kq): pixel k =
+//               4 kk + kq of token n -- per kk one coalesced read of a whole image row segment), A operand = the
+//               transposed conv weight from LDS, 16 embedding columns per tile, two tiles (one 128-byte line of every
+//               token) per loop iteration.
+// The extra tokens (time sinusoid, label embedding) of an image are written by the workgroup that owns its first patch rows,
+// one column per thread.
+// ------------------------------------------------------------------------------------------
+template <int P, int C>
+__global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
+    constexpr int PD = P * P * C, KK = PD / 4, KK4 = (KK + 3) / 4;
+    static_assert(PD % 4 == 0, "k-steps of 4");
+    extern __shared__ __attribute__((aligned(16))) char emb_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(emb_lds);            // [D / 32][2][KK4][64 lanes] x 4 k-steps
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int D = a.D, S = a.S, NP = D / 32;
+    const int pass = blockIdx.x * 8 + wave, b = pass >> 4, gy = pass & 15;
+    const bool valid = b < a.B;
+    if (blockIdx.x == 0 && tid == 0) a.st->t_final = a.st->t;   // handed to the step's last kernel (StepState)
+
+    // B operand: pixel k = 4 kk + kq of token n (k = (c, p1, p2) as in the reference's Conv2d weight [D, C, P, P])
+    float pv[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int k = 4 * kk + kq, c = k / (P * P), p1 = (k / P) % P, p2 = k % P;
+        pv[kk] = valid ? a.x_img[(((long long)b * C + c) * S + gy * P + p1) * S + n * P + p2] : 0.f;
+    }
+    // A operand image -> LDS, all loads of a thread before its first write
+    {
+        const int items = NP * 2 * KK4 * 64;
+        constexpr int MAXI = 16;                               // items per thread: D = 1024, PD = 16 -> 8; D = 768, PD = 48 -> 18 (two rounds)
+        for (int base = 0; base < items; base += 512 * MAXI) {
+            f32x4 v[MAXI];
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int item = base + tid + 512 * i;
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (item < items) {
+                    const int l = item & 63, kk4 = (item >> 6) % KK4, ph = (item >> 6) / KK4;   // ph = 2 p + half
+                    const int col = 16 * ph + (l & 15);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kk = 4 * kk4 + j;
+                        if (kk < KK) v[i][j] = a.wt[(long long)(4 * kk + (l >> 4)) * D + col];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int item = base + tid + 512 * i;
+                if (item < items) wl[item] = v[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        const long long l0 = a.extras + gy * 16 + n;
+        float* xrow = a.x_tok + ((long long)b * a.L + l0) * D + 4 * kq;
+        const float* prow = a.pos + l0 * D + 4 * kq;
+        const float* brow = a.bias + 4 * kq;
+        const f32x4* wlp = wl + lane;
+        // pos_embed / bias quads of pair p + 1 are requested before pair p computes (a load behind every iteration's
+        // stores would expose one L2 round trip per pair)
+        f32x4 pe = *reinterpret_cast<const f32x4*>(prow), po = *reinterpret_cast<const f32x4*>(prow + 16);
+        f32x4 be = *reinterpret_cast<const f32x4*>(brow), bo = *reinterpret_cast<const f32x4*>(brow + 16);
+        for (int p = 0; p < NP; ++p) {
+            f32x4 acc_e = {0.f, 0.f, 0.f, 0.f}, acc_o = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 pe_c = pe, po_c = po, be_c = be, bo_c = bo;
+            const int pn = p + 1 < NP ? p + 1 : p;
+            pe = *reinterpret_cast<const f32x4*>(prow + 32 * pn); po = *reinterpret_cast<const f32x4*>(prow + 32 * pn + 16);
+            be = *reinterpret_cast<const f32x4*>(brow + 32 * pn); bo = *reinterpret_cast<const f32x4*>(brow + 32 * pn + 16);
+#pragma unroll
+            for (int kk4 = 0; kk4 < KK4; ++kk4) {
+                const f32x4 we = wlp[((2 * p) * KK4 + kk4) * 64], wo = wlp[((2 * p + 1) * KK4 + kk4) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * kk4 + j < KK) {
+                        acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(we[j], pv[4 * kk4 + j], acc_e, 0, 0, 0);
+                        acc_o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[j], pv[4 * kk4 + j], acc_o, 0, 0, 0);
+                    }
+                }
+            }
+            // lane (n, kq) holds columns 32 p + 4 kq + {0..3} (even tile) and 32 p + 16 + 4 kq + {0..3} (odd tile) of token n:
+            // the four lanes of a token write 64 contiguous bytes per store, the two stores one 128-byte line
+            *reinterpret_cast<f32x4*>(xrow + 32 * p) = (acc_e + be_c) + pe_c;
+            *reinterpret_cast<f32x4*>(xrow + 32 * p + 16) = (acc_o + bo_c) + po_c;
+        }
+    }
+    if (((blockIdx.x * 8) & 15) == 0 && (int)(blockIdx.x * 8) / 16 < a.B) {   // the image's extra tokens: [label,] time (reference models/uvit.py:356-365)
+        const int bb = (blockIdx.x * 8) >> 4;
+        const float t_raw = a.t_vec ? a.t_vec[bb] : a.st->t_model;
+        const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
+        const int halfd = D / 2;
+        for (int row = 0; row < a.extras; ++row)
+            for (int d = tid; d < D; d += 512) {
+                float v;
+                if (row == a.extras - 1) {
+                    const int i = d < halfd ? d : d - halfd;
+                    const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
+                    v = d < halfd ? cosf(arg) : (d < 2 * halfd ? sinf(arg) : 0.f);
+                } else {
+                    long long yy = a.y[bb];
+                    yy = yy < 0 ? 0 : (yy >= a.num_classes ? a.num_classes - 1 : yy);
+                    v = a.label_emb[yy * D + d];
+                }
+                a.x_tok[((long long)bb * a.L + row) * D + d] = v + a.pos[(long long)row * D + d];
+            }
+    }
+    if (blockIdx.x == gridDim.x - 1) {   // padding rows of the workspace
+        const long long first = (long long)a.B * a.L * D, count = ((long long)a.Mp - (long long)a.B * a.L) * D;
+        for (long long i = tid; i < count; i += 512) a.x_tok[first + i] = 0.f;
     }
 }
 
@@ -403,6 +524,33 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
     const int tiles = (S + 15) / 16;
     const int b = blockIdx.x / (tiles * tiles), ty = (blockIdx.x / tiles) % tiles, tx = blockIdx.x % tiles;
     const int tid = threadIdx.x;
+    const int ly = tid >> 4, lx = tid & 15, y = ty * 16 + ly, x = tx * 16 + lx;
+    const bool inside = y < S && x < S;
+    // Everything that does not depend on the decoder output is requested / computed first, so that its latency (step
+    // state -> coefficient row, the x_t pixels, the Philox normals) overlaps the halo gather instead of following it:
+    // the kernel is a chain of dependent memory round trips, not bandwidth.
+    const int t = a.st->t_final;
+    const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
+    float xin[4] = {0.f, 0.f, 0.f, 0.f}, zin[4] = {0.f, 0.f, 0.f, 0.f};
+    if (inside && a.x_out) {
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            if (co < C) {
+                const long long e = (((long long)b * C + co) * S + y) * S + x;
+                xin[co] = a.x_in[e];
+                if (t > 0 && a.noise_mode == 1) zin[co] = a.z[e];
+            }
+        }
+    }
+    float wc[4][4][9], bc[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        bc[co] = co < C ? a.bconv[co] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wc[co][ci][k] = (co < C && ci < C) ? a.wconv[(co * C + ci) * 9 + k] : 0.f;
+    }
     for (int idx = tid; idx < 18 * 18; idx += 256) {
         const int hy = idx / 18, hx = idx % 18;
         const int yy = ty * 16 + hy - 1, xx = tx * 16 + hx - 1;
@@ -411,47 +559,50 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
                            (in ? ((yy % P) * P + (xx % P)) * C : 0);
         for (int ci = 0; ci < C; ++ci) u[ci][hy][hx] = in ? src[ci] : 0.f;
     }
+    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+    if (inside && a.x_out && t > 0 && a.noise_mode == 2)
+        zn = philox_normal4(a.st->seed, ((unsigned long long)b * S + y) * S + x, t);   // same pixel id as the untiled kernel
     __syncthreads();
-    const int ly = tid >> 4, lx = tid & 15, y = ty * 16 + ly, x = tx * 16 + lx;
     if (a.advance && blockIdx.x == 0 && tid == 0) {   // no block of this kernel reads t / t_model
-        const int tn = a.st->t_final - 1;
+        const int tn = t - 1;
         a.st->t = tn;
         a.st->t_model = (float)tn;
     }
-    if (y >= S || x >= S) return;
+    if (!inside) return;
     float acc[4];
 #pragma unroll
-    for (int co = 0; co < 4; ++co) acc[co] = co < C ? a.bconv[co] : 0.f;
+    for (int co = 0; co < 4; ++co) acc[co] = bc[co];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int yy = y + dy - 1, xx = x + dx - 1;
             if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;   // same skipped taps as the untiled kernel
-            for (int ci = 0; ci < C; ++ci) {
-                const float uv = u[ci][ly + dy][lx + dx];
 #pragma unroll
-                for (int co = 0; co < 4; ++co)
-                    if (co < C) acc[co] = fmaf(a.wconv[((co * C + ci) * 3 + dy) * 3 + dx], uv, acc[co]);
+            for (int ci = 0; ci < 4; ++ci) {
+                if (ci < C) {
+                    const float uv = u[ci][ly + dy][lx + dx];
+#pragma unroll
+                    for (int co = 0; co < 4; ++co)
+                        if (co < C) acc[co] = fmaf(wc[co][ci][dy * 3 + dx], uv, acc[co]);
+                }
             }
         }
-    const int t = a.st->t_final;
-    const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
-    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-    if (a.x_out && t > 0 && a.noise_mode == 2)
-        zn = philox_normal4(a.st->seed, ((unsigned long long)b * S + y) * S + x, t);   // same pixel id as the untiled kernel
-    for (int co = 0; co < C; ++co) {
-        const long long e = (((long long)b * C + co) * S + y) * S + x;
-        const float eps = acc[co];
-        if (a.eps_out) a.eps_out[e] = eps;
-        if (a.x_out) {
-            float v = cf.c1 * (a.x_in[e] - cf.c2 * eps);
-            if (t > 0) {
-                if (a.noise_mode == 1) v = v + sigma * a.z[e];
-                else if (a.noise_mode == 2) v = v + sigma * zn[co];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        if (co < C) {
+            const long long e = (((long long)b * C + co) * S + y) * S + x;
+            const float eps = acc[co];
+            if (a.eps_out) a.eps_out[e] = eps;
+            if (a.x_out) {
+                float v = cf.c1 * (xin[co] - cf.c2 * eps);
+                if (t > 0) {
+                    if (a.noise_mode == 1) v = v + sigma * zin[co];
+                    else if (a.noise_mode == 2) v = v + sigma * zn[co];
+                }
+                a.x_out[e] = v;
             }
-            a.x_out[e] = v;
         }
     }
 }
@@ -612,7 +763,23 @@ __global__ void __launch_bounds__(64) ee_batch_mean_kernel(const float* __restri
 
 }  // namespace
 
+bool embed_mfma_ok(const EmbedArgs& a, size_t& lds) {
+    const int pd = a.C * a.P * a.P;
+    lds = (size_t)(a.D / 32) * 2 * ((pd / 4 + 3) / 4) * 1024;
+    return a.S == 16 * a.P && a.D % 32 == 0 && pd % 4 == 0 && lds <= 156 * 1024 && a.L == a.extras + 256 &&
+           ((a.P == 4 && a.C == 3) || (a.P == 2 && a.C == 3) || (a.P == 2 && a.C == 4));
+}
+
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
+    size_t mlds = 0;
+    static const bool no_mfma = [] { const char* e = std::getenv("DD_EMBED_MFMA"); return e && e[0] == '0'; }();
+    if (!no_mfma && embed_mfma_ok(a, mlds)) {
+        const dim3 grid((unsigned)((a.B * 16 + 7) / 8));
+        if (a.P == 4) hipLaunchKernelGGL((embed_mfma_kernel<4, 3>), grid, dim3(512), mlds, s, a);
+        else if (a.C == 3) hipLaunchKernelGGL((embed_mfma_kernel<2, 3>), grid, dim3(512), mlds, s, a);
+        else hipLaunchKernelGGL((embed_mfma_kernel<2, 4>), grid, dim3(512), mlds, s, a);
+        return hipGetLastError();
+    }
     const int pd_ = a.C * a.P * a.P, nd_ = a.D / 256;
     if (a.D % 256 == 0) {
         const int chunks = (a.L + 63) / 64;
@@ -759,6 +926,9 @@ hipError_t init_rowops_kernels() {
     DD_HEAD_ATTR(512, 1) DD_HEAD_ATTR(512, 2) DD_HEAD_ATTR(512, 3) DD_HEAD_ATTR(512, 4)
     DD_HEAD_ATTR(256, 1) DD_HEAD_ATTR(256, 2) DD_HEAD_ATTR(256, 3) DD_HEAD_ATTR(256, 4)
 #undef DD_HEAD_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     return e;
 }
 
