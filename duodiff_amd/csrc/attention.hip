@@ -235,6 +235,13 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float p;
+                    // L = 256 + extras: the 9th key tile holds 1 or 2 real keys (registers 0, 1 of lane half 0); the other 14
+                    // registers are padded keys in both halves -- a literal 0 instead of exp2(-inf): a tenth of the kernel's
+                    // exponentials, which are what bounds it
+                    if (NKT == 9 && NT == 9 && k == 8 && e >= 2) {
+                        s[k][e] = 0.f;
+                        continue;
+                    }
 #if defined(DD_ATTN_ABLATE) && DD_ATTN_ABLATE == 5     // 5 = no exp (a multiply in its place)
                     p = fmaf(s[k][e], kScaleLog2e, -mxs) * 0.001f;
 #else
