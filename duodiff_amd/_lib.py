@@ -66,6 +66,7 @@ SIGNATURES = {
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 3),
+    "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_plan_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dd_last_sample_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -36,6 +36,12 @@ struct dd_ctx {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float timing[3] = {0, 0, 0};
     int num_cus = 256;           // CU count the persistent GEMM grids are sized for (dd_set_num_cus), a multiple of 8
+    // dd_sample's graphs run on context-owned staging copies of x / y, so a captured step does not depend on the caller's
+    // tensor addresses (reference get_samples allocates a fresh x per call: the graphs would be re-captured every time)
+    float* x_stage = nullptr;
+    int64_t* y_stage = nullptr;
+    size_t x_stage_elems = 0, y_stage_elems = 0;
+    long long graph_captures = 0;
 };
 
 namespace {
@@ -576,6 +582,8 @@ void dd_ctx_destroy(dd_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipFree(c->st);
     if (c->coef) (void)hipFree(c->coef);
+    if (c->x_stage) (void)hipFree(c->x_stage);
+    if (c->y_stage) (void)hipFree(c->y_stage);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -983,13 +991,35 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     const bool switching = a->late && a->t_switch > 0 && a->t_switch <= 1000;
     const int t_sw = 1000 - a->t_switch;  // the late model takes over AFTER this step (sampler.py:135-136)
 
+    // the loop runs on x_run / y_run: with graphs the context's staging buffers (copied in here, copied back at the end)
+    float* x_run = a->x_dev;
+    const int64_t* y_run = a->y_dev;
+    const size_t x_elems = (size_t)a->B * a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    if (a->use_graph) {
+        if (c->x_stage_elems < x_elems) {       // grows only: model graphs keyed on the old address are re-captured once
+            if (c->x_stage) (void)hipFree(c->x_stage);
+            c->x_stage = nullptr; c->x_stage_elems = 0;
+            DD_HIP(c, hipMalloc((void**)&c->x_stage, x_elems * sizeof(float)));
+            c->x_stage_elems = x_elems;
+        }
+        if (a->y_dev && c->y_stage_elems < (size_t)a->B) {
+            if (c->y_stage) (void)hipFree(c->y_stage);
+            c->y_stage = nullptr; c->y_stage_elems = 0;
+            DD_HIP(c, hipMalloc((void**)&c->y_stage, (size_t)a->B * sizeof(int64_t)));
+            c->y_stage_elems = (size_t)a->B;
+        }
+        DD_HIP(c, hipMemcpyAsync(c->x_stage, a->x_dev, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (a->y_dev) DD_HIP(c, hipMemcpyAsync(c->y_stage, a->y_dev, (size_t)a->B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+        x_run = c->x_stage;
+        y_run = a->y_dev ? c->y_stage : nullptr;
+    }
     auto get_graph = [&](dd_model* m) -> int {
-        GraphKey key{a->x_dev, a->y_dev, a->B, a->noise_mode, a->variance};
+        GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance};
         if (m->graph && m->gkey == key) return DD_OK;
         if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         hipGraph_t g = nullptr;
         DD_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_step(c, m, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
+        int r = enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
         hipError_t e2 = hipStreamEndCapture(s, &g);
         if (r) { if (g) (void)hipGraphDestroy(g); return r; }
         if (e2 != hipSuccess) return fail_hip(c, e2, "hipStreamEndCapture");
@@ -997,6 +1027,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         (void)hipGraphDestroy(g);
         if (e3 != hipSuccess) { m->graph = nullptr; return fail_hip(c, e3, "hipGraphInstantiate"); }
         m->gkey = key;
+        ++c->graph_captures;
         return DD_OK;
     };
 
@@ -1012,7 +1043,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         if (a->use_graph) {
             DD_HIP(c, hipGraphLaunch(cur->graph, s));
         } else {
-            rc = enqueue_step(c, cur, a->x_dev, a->y_dev, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
+            rc = enqueue_step(c, cur, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
             if (rc) return rc;
         }
         if (switching && t == t_sw) {
@@ -1023,8 +1054,11 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     }
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));
+    if (x_run != a->x_dev) DD_HIP(c, hipMemcpyAsync(a->x_dev, x_run, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
     return DD_OK;
 }
+
+long long dd_dev_graph_captures(dd_ctx* c) { return c ? c->graph_captures : -1; }
 
 int dd_last_sample_timing(dd_ctx* c, float out3[3]) {
     if (!c || !out3) return DD_ERR_INVALID;

@@ -88,127 +88,11 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedArgs a) {
     }
 }
 
-// Fast path for D % 256 == 0 (every shipped config): 64 token rows per workgroup, each thread owns
-// ND = D/256 embedding columns and keeps their PD = C*P*P patch-embed weights in registers, so the
-// inner loop is PD LDS-broadcast reads + ND*PD FMAs per token with no global weight traffic.
-template <int ND, int PD>
-__global__ void __launch_bounds__(256) embed_fast_kernel(const EmbedArgs a) {
-    constexpr int TOK = 64;
-    __shared__ __attribute__((aligned(16))) float patch[TOK][PD];
-    const int chunks = (a.L + TOK - 1) / TOK;
-    const int b = blockIdx.x / chunks, r0 = (blockIdx.x % chunks) * TOK;
-    const int tid = threadIdx.x;
-    const int g = a.S / a.P, PP = a.P * a.P;
-    if (blockIdx.x == 0 && tid == 0) a.st->t_final = a.st->t;   // handed to the step's last kernel (StepState)
-    if (b >= a.B) {  // padding rows of the workspace
-        const long long row0 = (long long)a.B * a.L + (long long)(blockIdx.x - a.B * chunks) * TOK;
-        for (int j = 0; j < TOK; ++j) {
-            const long long row = row0 + j;
-            if (row < a.Mp)
-                for (int d = tid; d < a.D; d += 256) a.x_tok[row * a.D + d] = 0.f;
-        }
-        return;
-    }
-    for (int idx = tid; idx < TOK * PD; idx += 256) {
-        const int j = idx / PD, k = idx % PD, row = r0 + j;
-        float v = 0.f;
-        if (row >= a.extras && row < a.L) {
-            const int n = row - a.extras, gy = n / g, gx = n % g;
-            const int c = k / PP, p1 = (k / a.P) % a.P, p2 = k % a.P;
-            v = a.x_img[(((long long)b * a.C + c) * a.S + gy * a.P + p1) * a.S + gx * a.P + p2];
-        }
-        patch[j][k] = v;
-    }
-    float w[ND][PD], bias[ND];
-#pragma unroll
-    for (int n = 0; n < ND; ++n) {
-        bias[n] = a.bias[tid + 256 * n];
-#pragma unroll
-        for (int k = 0; k < PD; ++k) w[n][k] = a.wt[(long long)k * a.D + tid + 256 * n];
-    }
-    __syncthreads();
-    const float t_raw = a.t_vec ? a.t_vec[b] : a.st->t_model;
-    const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
-    const int halfd = a.D / 2;
-    // Tokens in groups of U: the U pos_embed rows of a group are requested together, before any of the group's stores (a
-    // load queued behind a store of the same wave waits for that store -- vmcnt retires in order), so the loop pays one
-    // memory latency per U tokens instead of one per token (what bounded this kernel: ~0.6 us per token and workgroup).
-    constexpr int U = 8;
-    static_assert(TOK % U == 0, "token groups");
-    for (int j0 = 0; j0 < TOK; j0 += U) {
-        if (r0 + j0 >= a.L) break;
-        float posv[U][ND];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = r0 + j0 + u < a.L ? r0 + j0 + u : a.L - 1;
-#pragma unroll
-            for (int n = 0; n < ND; ++n) posv[u][n] = a.pos[(long long)row * a.D + tid + 256 * n];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u, row = r0 + j;
-            if (row >= a.L) break;
-            float acc[ND];
-            if (row >= a.extras) {
-                if constexpr (ND % 2 == 0) {
-                    // column pairs as 2-vectors: hipcc emits v_pk_fma_f32 (two FMAs per lane and issue slot).  Per element
-                    // the same fmaf chain as below.
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    f32x2 acc2[ND / 2];
-#pragma unroll
-                    for (int n = 0; n < ND / 2; ++n) acc2[n] = f32x2{0.f, 0.f};
-#pragma unroll
-                    for (int k4 = 0; k4 < PD / 4; ++k4) {
-                        const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int n = 0; n < ND / 2; ++n)
-                                acc2[n] = __builtin_elementwise_fma(f32x2{w[2 * n][k4 * 4 + e], w[2 * n + 1][k4 * 4 + e]}, f32x2{p[e], p[e]}, acc2[n]);
-                    }
-#pragma unroll
-                    for (int n = 0; n < ND / 2; ++n) { acc[2 * n] = acc2[n][0]; acc[2 * n + 1] = acc2[n][1]; }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < ND; ++n) acc[n] = 0.f;
-#pragma unroll
-                    for (int k4 = 0; k4 < PD / 4; ++k4) {
-                        const f32x4 p = *reinterpret_cast<const f32x4*>(&patch[j][k4 * 4]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int n = 0; n < ND; ++n) acc[n] = fmaf(w[n][k4 * 4 + e], p[e], acc[n]);
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < ND; ++n) acc[n] += bias[n];
-            } else if (row == a.extras - 1) {
-#pragma unroll
-                for (int n = 0; n < ND; ++n) {
-                    const int d = tid + 256 * n, i = d < halfd ? d : d - halfd;
-                    const float arg = tt * expf((-9.210340371976184f * (float)i) / (float)halfd);
-                    acc[n] = d < halfd ? cosf(arg) : sinf(arg);
-                }
-            } else {
-                long long yy = a.y[b];
-                yy = yy < 0 ? 0 : (yy >= a.num_classes ? a.num_classes - 1 : yy);
-#pragma unroll
-                for (int n = 0; n < ND; ++n) acc[n] = a.label_emb[yy * a.D + tid + 256 * n];
-            }
-#pragma unroll
-            for (int n = 0; n < ND; ++n) {
-                const int d = tid + 256 * n;
-                a.x_tok[((long long)b * a.L + row) * a.D + d] = acc[n] + posv[u][n];
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Patch embedding on the matrix pipe (exact fp32: v_mfma_f32_16x16x4_f32 == an fmaf chain in k order), for image grids
-// of 16 patches per row (every shipped config).  The VALU kernel above is bound by its PD * D FMAs per token (0.8 G per
-// launch = 26 us of pure VALU issue); the f32 MFMA does the same arithmetic at twice that rate and leaves the vector
-// pipe to the address math, so the launch approaches its 67 MB of output writes.
+// of 16 patches per row (every shipped config; other grids take the generic kernel above).  A VALU kernel is bound by its
+// PD * D FMAs per token (0.8 G per launch = 26 us of pure vector issue -- round 1's embed_fast_kernel, 68 us); the f32 MFMA
+// does the same arithmetic at twice that rate and leaves the vector pipe to the address math.
 //   workgroup = 8 waves = 8 patch rows of an image (2 workgroups per image: one per CU at B = 128, a single round);
 //   wave      = one patch row = 16 tokens as the MFMA N dimension: B operand = the 16 patches (lane (n, kq): pixel k =
 //               4 kk + kq of token n -- per kk one coalesced read of a whole image row segment), A operand = the
@@ -779,19 +663,6 @@ hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
         else if (a.C == 3) hipLaunchKernelGGL((embed_mfma_kernel<2, 3>), grid, dim3(512), mlds, s, a);
         else hipLaunchKernelGGL((embed_mfma_kernel<2, 4>), grid, dim3(512), mlds, s, a);
         return hipGetLastError();
-    }
-    const int pd_ = a.C * a.P * a.P, nd_ = a.D / 256;
-    if (a.D % 256 == 0) {
-        const int chunks = (a.L + 63) / 64;
-        const long long pad = (long long)a.Mp - (long long)a.B * a.L;
-        const dim3 grid(a.B * chunks + (int)((pad + 63) / 64));
-#define DD_EMB(ND, PD)                                                              \
-    if (nd_ == ND && pd_ == PD) {                                                   \
-        hipLaunchKernelGGL((embed_fast_kernel<ND, PD>), grid, dim3(256), 0, s, a);  \
-        return hipGetLastError();                                                   \
-    }
-        DD_EMB(2, 48) DD_EMB(3, 48) DD_EMB(2, 12) DD_EMB(4, 16)
-#undef DD_EMB
     }
     const int per_img = (a.L + kEmbedTok - 1) / kEmbedTok;
     const long long pad_rows = (long long)a.Mp - (long long)a.B * a.L;

@@ -24,6 +24,10 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
                const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out,
                const float* ao_host, const float* wproj, const float* bproj);
 
+/* Number of hipGraph captures dd_sample has made on this context so far (tests: a second call with other tensors of the
+ * same shape must not capture again). */
+long long dd_dev_graph_captures(dd_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,35 @@ def test_switch_and_graph_replay_match_manual_steps():
     assert torch.isfinite(xm).all()
 
 
+def test_graphs_are_not_recaptured_for_new_tensors():
+    """reference get_samples allocates a fresh x per call (sampler.py:98); dd_sample's graphs run on context-owned staging
+    buffers, so a second call with other tensors of the same shape replays the captured graphs (and still writes its
+    result into the caller's tensor)."""
+    from duodiff_amd.engine import sample_loop
+    m_s, _ = _uvit(dict(TINY, depth=1), 21, "bf16")
+    m_f, _ = _uvit(dict(TINY, depth=3), 22, "bf16")
+    B = 3
+    es, ef = m_s.engine_model(B), m_f.engine_model(B)
+    lib, h = es.ctx.lib, es.ctx.handle
+    stream = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(9)
+    xa, xb = torch.randn(B, 3, 8, 8, generator=g).cuda(), torch.randn(B, 3, 8, 8, generator=g).cuda()
+    with torch.cuda.stream(stream):
+        ra = xa.clone()
+        sample_loop(es.ctx, es, ef, ra, t_switch=3, t_start=999, t_end=994, seed=5, noise="philox", use_graph=True, stream=stream)
+        stream.synchronize()
+        n1 = lib.dd_dev_graph_captures(h)
+        rb = xb.clone()                                  # a different allocation
+        sample_loop(es.ctx, es, ef, rb, t_switch=3, t_start=999, t_end=994, seed=5, noise="philox", use_graph=True, stream=stream)
+        stream.synchronize()
+        n2 = lib.dd_dev_graph_captures(h)
+        eb = xb.clone()
+        sample_loop(es.ctx, es, ef, eb, t_switch=3, t_start=999, t_end=994, seed=5, noise="philox", use_graph=False, stream=stream)
+        stream.synchronize()
+    assert n2 == n1, f"{n2 - n1} graph captures for a second call of the same shape"
+    assert torch.equal(rb, eb) and not torch.equal(rb, xb) and torch.isfinite(rb).all()
+
+
 def test_philox_noise_is_standard_normal():
     m, mp = _uvit(dict(TINY), 21, "bf16")
     B = 64
