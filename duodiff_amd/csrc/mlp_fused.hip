@@ -83,10 +83,12 @@ __device__ __forceinline__ void lds_quad(f32x4& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
 
-// exact-erf GELU for a bf16-rounded result: gelu(v) = hv + hv * s * P(s^2), s = med3(v, +-3.8), hv = v/2, P the degree-6
+// exact-erf GELU for a bf16-rounded result: gelu(v) = v * (0.5 + s * P'(s^2)), s = med3(v, +-3.8), P' = P / 2 with P the degree-6
 // minimax polynomial of erf(s/sqrt2)/s (same coefficients as the GEMM epilogue in gemm.hip: |erf error| <= 1.3e-4, GELU
 // abs error <= 2.4e-4).  TWO values are evaluated together as interleaved chains (no instruction reads the result of the
-// one in front of it), cut into 8 pieces of 3 VALU instructions; one piece sits in the gap behind one MFMA.
+// one in front of it), cut into 8 pieces of at most 3 VALU instructions (21 in all: at one wave per SIMD the loop is bound by
+// vector issue -- a lone wave issues a VALU instruction every ~8 clocks, profiles/r02/exp_rate.txt -- so every instruction
+// counts); one piece sits in the gap behind one MFMA.
 struct GeluConst { float hi, c5; };   // 3.8 and the s^12 coefficient live in VGPRs (VOP3 / fmamk take no second literal)
 struct GeluPair { float sa, s2a, pa, ha, sb, s2b, pb, hb; };
 
@@ -98,13 +100,13 @@ struct GeluPair { float sa, s2a, pa, ha, sb, s2b, pb, hb; };
 #define DD_S_MFMA "s_waitcnt lgkmcnt(%[lg])\n\tv_mfma_f32_32x32x16_bf16 %[acc], %[wa], %[xb], %[acc]"
 #define DD_S_READ "\n\tds_read_b128 %[wa], %[la] offset:%[lo]"
 #define DD_S_G0 "\n\tv_med3_f32 %[sa], %[va], %[kn], %[kh]\n\tv_med3_f32 %[sb], %[vb], %[kn], %[kh]\n\tv_mul_f32 %[s2a], %[sa], %[sa]"
-#define DD_S_G1 "\n\tv_mul_f32 %[s2b], %[sb], %[sb]\n\tv_fmamk_f32 %[pa], %[s2a], 0x339d7172, %[kc]\n\tv_fmamk_f32 %[pb], %[s2b], 0x339d7172, %[kc]"
-#define DD_S_G2 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x38fe87ac\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x38fe87ac\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xbaf43309"
-#define DD_S_G3 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xbaf43309\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3c98a4c9\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3c98a4c9"
-#define DD_S_G4 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xbe069818\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xbe069818\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3f4c1f5c"
-#define DD_S_G5 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3f4c1f5c\n\tv_mul_f32 %[pa], %[pa], %[sa]\n\tv_mul_f32 %[pb], %[pb], %[sb]"
-#define DD_S_G6 "\n\tv_mul_f32 %[ha], 0.5, %[va]\n\tv_mul_f32 %[hb], 0.5, %[vb]\n\tv_fmac_f32 %[ha], %[ha], %[pa]"
-#define DD_S_G7 "\n\tv_fmac_f32 %[hb], %[hb], %[pb]\n\tv_cvt_pk_bf16_f32 %[out], %[ha], %[hb]"
+#define DD_S_G1 "\n\tv_mul_f32 %[s2b], %[sb], %[sb]\n\tv_fmamk_f32 %[pa], %[s2a], 0x331d7172, %[kc]\n\tv_fmamk_f32 %[pb], %[s2b], 0x331d7172, %[kc]"
+#define DD_S_G2 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x387e87ac\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x387e87ac\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xba743309"
+#define DD_S_G3 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xba743309\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3c18a4c9\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3c18a4c9"
+#define DD_S_G4 "\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0xbd869818\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0xbd869818\n\tv_fmaak_f32 %[pa], %[pa], %[s2a], 0x3ecc1f5c"
+#define DD_S_G5 "\n\tv_fmaak_f32 %[pb], %[pb], %[s2b], 0x3ecc1f5c\n\tv_fmaak_f32 %[ha], %[sa], %[pa], 0x3f000000\n\tv_fmaak_f32 %[hb], %[sb], %[pb], 0x3f000000"
+#define DD_S_G6 "\n\tv_mul_f32 %[ha], %[ha], %[va]\n\tv_mul_f32 %[hb], %[hb], %[vb]"
+#define DD_S_G7 "\n\tv_cvt_pk_bf16_f32 %[out], %[ha], %[hb]"
 #define DD_GAP_ASM(STR, ACC_C)                                                                                          \
     asm volatile(STR                                                                                                    \
                  : [acc] ACC_C(acc), [wa] "+v"(wa), [sa] "+v"(r.sa), [s2a] "+v"(r.s2a), [pa] "+v"(r.pa), [ha] "+v"(r.ha),  \
@@ -144,9 +146,9 @@ __device__ __forceinline__ void gelu_piece(float va, float vb, const GeluConst& 
     else if constexpr (K == 2) asm volatile(DD_S_G2 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
     else if constexpr (K == 3) asm volatile(DD_S_G3 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
     else if constexpr (K == 4) asm volatile(DD_S_G4 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2a] "v"(r.s2a), [s2b] "v"(r.s2b));
-    else if constexpr (K == 5) asm volatile(DD_S_G5 : [pa] "+v"(r.pa), [pb] "+v"(r.pb) : [s2b] "v"(r.s2b), [sa] "v"(r.sa), [sb] "v"(r.sb));
-    else if constexpr (K == 6) asm volatile(DD_S_G6 : [ha] "+v"(r.ha), [hb] "+v"(r.hb) : [va] "v"(va), [vb] "v"(vb), [pa] "v"(r.pa));
-    else asm volatile(DD_S_G7 : [out] "+v"(out), [hb] "+v"(r.hb) : [ha] "v"(r.ha), [pb] "v"(r.pb));
+    else if constexpr (K == 5) asm volatile(DD_S_G5 : [pb] "+v"(r.pb), [ha] "+v"(r.ha), [hb] "+v"(r.hb) : [s2b] "v"(r.s2b), [sa] "v"(r.sa), [sb] "v"(r.sb), [pa] "v"(r.pa));
+    else if constexpr (K == 6) asm volatile(DD_S_G6 : [ha] "+v"(r.ha), [hb] "+v"(r.hb) : [va] "v"(va), [vb] "v"(vb));
+    else asm volatile(DD_S_G7 : [out] "+v"(out) : [ha] "v"(r.ha), [hb] "v"(r.hb));
 }
 
 // 16-byte global load straight into accumulator registers (AGPRs are legal vector-memory destinations on gfx950): the 64
@@ -422,7 +424,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     const unsigned lds_hi = lds_lo + 65536u;
     const unsigned bias_lo = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + C::RING + h * 64;
     constexpr int PD = C::F < 8 ? C::F : 8;    // fragment reads in flight ahead of their MFMA: covers ~250 cycles of LDS latency
-    const GeluConst gk{3.8f, -4.544908101e-06f};
+    const GeluConst gk{3.8f, 0.5f * -4.544908101e-06f};     // (the polynomial's coefficients are halved: 0.5 * erf(s / sqrt2) / s)
 
     // LDS offset of fragment f of ring slot `slot` relative to lds_lo (compile-time)
     auto frag_off = [](int slot, int f) constexpr { return slot * C::BLK + f * 1024; };
