@@ -54,6 +54,14 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 __device__ __forceinline__ void glds16u(const char* ubase, unsigned voff, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)(ubase + voff), (lptr_t)lds_dst, 16, 0, 0);
 }
+// Request j of a block (1 KB apart in the image and in the ring): the instruction's immediate offset -- it applies to the
+// global AND the LDS address -- carries (j & 3) KB, so four requests share one 64-bit address computation and one M0
+// setup.  At one wave per SIMD those were two of the three instructions every request cost (15 us of a fused launch).
+template <int J>
+__device__ __forceinline__ void glds16u_j(const char* ublock, unsigned voff, char* lds_block) {
+    constexpr int HI = (J >> 2) * 4096, IMM = (J & 3) * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(ublock + HI + voff), (lptr_t)(lds_block + HI), 16, IMM, 0);
+}
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32
     typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
@@ -223,8 +231,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     auto dma_block = [&](int b, int slot) {
         const char* src = uniform_ptr((PROJ ? wproj : wmlp) + (size_t)b * C::BLK);
         char* dst = smem + slot * C::BLK + (wave * C::FPW) * 1024;
-#pragma unroll
-        for (int j = 0; j < C::FPW; ++j) glds16u(src + j * 1024, dma_voff, dst + j * 1024);
+        [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
     };
 
     // prologue: the first three blocks of the stream (W1(c0), W2(c0), W1(c0+1); with PROJ the first three Wproj blocks) in
@@ -354,8 +361,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                         // stream position t + 3: Wproj block, or (t + 3 >= NT) block t + 3 - NT of the MLP part
                         const char* src = uniform_ptr(a.wimg + (size_t)(t + 3) * C::BLK);
                         char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
-#pragma unroll
-                        for (int j = 0; j < C::FPW; ++j) glds16u(src + j * 1024, dma_voff, dst + j * 1024);
+                        [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
                     }
                     constexpr int gn = g + PDp, left = NGp - 1 - g, LG = left < PDp - 1 ? left : PDp - 1;
                     constexpr bool RD = gn < NGp;
@@ -530,8 +536,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 #if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1     // 1 = no DMA in the loop
                 if constexpr (g % DSTEP == DSTEP / 2) {
                     constexpr int j = (g % C::F) / DSTEP;
-                    if constexpr (g < C::F) glds16u(src_e + j * 1024, dma_voff, dst_e + j * 1024);
-                    else glds16u(src_m + j * 1024, dma_voff, dst_m + j * 1024);
+                    if constexpr (g < C::F) glds16u_j<j>(src_e, dma_voff, dst_e);
+                    else glds16u_j<j>(src_m, dma_voff, dst_m);
                 }
 #endif
             }(), ...);
