@@ -105,7 +105,8 @@ struct GeluPair { float sa, s2a, pa, ha, sb, s2b, pb, hb; };
 //     ; [piece K of the GELU pair (va, vb)]
 // KIND 0: S^T += W1 fragment . X^T, accumulator in VGPRs;  KIND 1: Y^T tile += W2 fragment . P^T, accumulator in AGPRs.
 // Every operand is declared for every variant (unused ones cost nothing); the GELU registers are read-write throughout.
-#define DD_S_MFMA "s_waitcnt lgkmcnt(%[lg])\n\tv_mfma_f32_32x32x16_bf16 %[acc], %[wa], %[xb], %[acc]"
+#define DD_S_MFMA_W "s_waitcnt lgkmcnt(%[lg])\n\tv_mfma_f32_32x32x16_bf16 %[acc], %[wa], %[xb], %[acc]"
+#define DD_S_MFMA_N "v_mfma_f32_32x32x16_bf16 %[acc], %[wa], %[xb], %[acc]"     // LG < 0: the gap in front already waited for this fragment
 #define DD_S_READ "\n\tds_read_b128 %[wa], %[la] offset:%[lo]"
 #define DD_S_G0 "\n\tv_med3_f32 %[sa], %[va], %[kn], %[kh]\n\tv_med3_f32 %[sb], %[vb], %[kn], %[kh]\n\tv_mul_f32 %[s2a], %[sa], %[sa]"
 #define DD_S_G1 "\n\tv_mul_f32 %[s2b], %[sb], %[sb]\n\tv_fmamk_f32 %[pa], %[s2a], 0x331d7172, %[kc]\n\tv_fmamk_f32 %[pb], %[s2b], 0x331d7172, %[kc]"
@@ -121,26 +122,24 @@ struct GeluPair { float sa, s2a, pa, ha, sb, s2b, pb, hb; };
                    [sb] "+v"(r.sb), [s2b] "+v"(r.s2b), [pb] "+v"(r.pb), [hb] "+v"(r.hb), [out] "+v"(out)                 \
                  : [xb] "v"(xb), [la] "v"(la), [va] "v"(va), [vb] "v"(vb), [kn] "s"(-3.8f), [kh] "v"(k.hi), [kc] "v"(k.c5), \
                    [lg] "i"(LG), [lo] "i"(LO))
-#define DD_GAP_K(KK, GSTR, ACC_C)                                              \
-    else if constexpr (K == KK) {                                             \
-        if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ GSTR, ACC_C);      \
-        else DD_GAP_ASM(DD_S_MFMA GSTR, ACC_C);                               \
+#define DD_GAP_SEL(GSTR, ACC_C)                                                    \
+    if constexpr (LG >= 0) {                                                      \
+        if constexpr (READ) DD_GAP_ASM(DD_S_MFMA_W DD_S_READ GSTR, ACC_C);        \
+        else DD_GAP_ASM(DD_S_MFMA_W GSTR, ACC_C);                                 \
+    } else {                                                                      \
+        if constexpr (READ) DD_GAP_ASM(DD_S_MFMA_N DD_S_READ GSTR, ACC_C);        \
+        else DD_GAP_ASM(DD_S_MFMA_N GSTR, ACC_C);                                 \
     }
+#define DD_GAP_K(KK, GSTR, ACC_C) else if constexpr (K == KK) { DD_GAP_SEL(GSTR, ACC_C) }
 template <int KIND, int LG, bool READ, int LO, int K>
 __device__ __forceinline__ void gap_stmt(f32x16& acc, bf16x8& wa, const bf16x8& xb, unsigned la, float va, float vb,
                                          const GeluConst& k, GeluPair& r, unsigned& out) {
     if constexpr (KIND == 0) {
-        if constexpr (K < 0) {
-            if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ, "+v");
-            else DD_GAP_ASM(DD_S_MFMA, "+v");
-        }
+        if constexpr (K < 0) { DD_GAP_SEL("", "+v") }
         DD_GAP_K(0, DD_S_G0, "+v") DD_GAP_K(1, DD_S_G1, "+v") DD_GAP_K(2, DD_S_G2, "+v") DD_GAP_K(3, DD_S_G3, "+v")
         DD_GAP_K(4, DD_S_G4, "+v") DD_GAP_K(5, DD_S_G5, "+v") DD_GAP_K(6, DD_S_G6, "+v") DD_GAP_K(7, DD_S_G7, "+v")
     } else {
-        if constexpr (K < 0) {
-            if constexpr (READ) DD_GAP_ASM(DD_S_MFMA DD_S_READ, "+a");
-            else DD_GAP_ASM(DD_S_MFMA, "+a");
-        }
+        if constexpr (K < 0) { DD_GAP_SEL("", "+a") }
         DD_GAP_K(0, DD_S_G0, "+a") DD_GAP_K(1, DD_S_G1, "+a") DD_GAP_K(2, DD_S_G2, "+a") DD_GAP_K(3, DD_S_G3, "+a")
         DD_GAP_K(4, DD_S_G4, "+a") DD_GAP_K(5, DD_S_G5, "+a") DD_GAP_K(6, DD_S_G6, "+a") DD_GAP_K(7, DD_S_G7, "+a")
     }
@@ -508,8 +507,13 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 constexpr int LO = gn < C::F ? frag_off(SLOT_A, gn) : gn < NG ? frag_off(SLOT_B, gn - C::F) : frag_off(SLOT_N, gn - NG);
                 constexpr int LOA = LO < 65536 ? LO : LO - 65536;
                 const unsigned la = LO < 65536 ? lds_lo : lds_hi;
-                // the bias reads issued behind gap KB are younger than the fragments of gaps KB+1 .. KB+PD
-                constexpr int LG = PD - 1 + ((g > KB && g <= KB + PD) ? 4 : 0);
+                // One counted wait per PAIR of gaps (at one wave per SIMD every instruction costs an issue slot the MFMA pipe
+                // waits for): the even gap waits until the fragment of the odd gap behind it has landed (LDS reads return
+                // in order, so its own has too).  Younger than fragment g+1 at that point: PD - 2 fragment reads, plus the 4
+                // bias reads issued behind gap KB for the fragments requested before them.
+                constexpr int lg_next = PD - 1 + ((g + 1 > KB && g + 1 <= KB + PD) ? 4 : 0);
+                constexpr int LG = (g & 1) ? -1 : lg_next - 1 - (g == KB ? 4 : 0);
+                static_assert(KB % 2 == 0 || C::F < 4, "pair waits assume an even bias gap");
 #if defined(DD_MLP_ABLATE) && DD_MLP_ABLATE == 3      // development builds only (tools/build_variant.py): 3 = no GELU
                 constexpr int K = -1;
                 pw[(g * PPG) >> 3] = 0x3c003c00u;
