@@ -1,7 +1,9 @@
-// Fused U-ViT MLP for gfx950:  x += fc2( GELU_erf( fc1(h) + b1 ) ) + b2   in ONE launch, bf16 MFMA operands,
-// fp32 accumulation and fp32 residual stream.  Replaces reference models/uvit.py:86-92 (Mlp.forward) plus the
-// residual add of Block.forward (models/uvit.py:207).  The hidden activation [M, 4D] (135 MB per block at B = 128)
-// never exists: not in HBM, not in LDS.
+// Fused tail of a U-ViT block for gfx950, ONE launch, bf16 MFMA operands, fp32 accumulation and fp32 residual stream:
+//     x1 = x + proj(ao) + b          (optional; reference models/uvit.py:166 + the residual add of :206)
+//     h2 = norm2(x1)                 (optional, from the accumulators; :207)
+//     y  = x1 + fc2( GELU_erf( fc1(h2) + b1 ) ) + b2        (:86-92, :207)
+//     outputs: y (fp32, in place), bf16(y) (long-skip / next GEMM operand), norm1_next(y) in bf16 (optional; next block's :206)
+// Neither x1, h2 nor the hidden activation [M, 4D] (135 MB per block at B = 128) ever exists in HBM or LDS.
 //
 // Shape of the computation (D = embedding dim <= 512, hidden = 4D, both multiples of 32):
 //   * a workgroup owns 128 token rows, a wave 32 of them -- for ALL D output columns, so one wave carries its
