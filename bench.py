@@ -241,7 +241,7 @@ def main():
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "bytes/launch from the committed rocprofv3 --pmc profile profiles/r02/pmc_traffic.json (not measured in this run)",
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "mlp_fused_kernel<512> (+ proj_rows / mlp_reduce for the extra-token rows): attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d" % (M_rows, D_, H_),
+                         "kernel": "mlp_fused_kernel<512>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d (the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (M_rows, D_, H_),
                          "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
                          "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,

@@ -447,7 +447,8 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
                 if (int rc = mark()) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
-                if (int rc = mark()) return rc;
+                if (int rc = mark()) return rc;              // (the event pair brackets the fused kernel alone)
+                DD_HIP(c, launch_mlp_reduce(fa, D, s));
                 continue;
             }
         }
@@ -1186,6 +1187,7 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         DD_TRY(launch_proj_rows(a, D, s));
     }
     DD_TRY(launch_mlp_fused(a, D, s));
+    DD_TRY(launch_mlp_reduce(a, D, s));
     DD_TRY(hipStreamSynchronize(s));
     DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));
     if (out_host) DD_TRY(hipMemcpy(out_host, dO, (size_t)M * D * 2, hipMemcpyDeviceToHost));
@@ -1194,7 +1196,7 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         hipEvent_t e0 = nullptr, e1 = nullptr;
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) DD_TRY(launch_mlp_fused(a, D, s));
+        for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(a, D, s)); }
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

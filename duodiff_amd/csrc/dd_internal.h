@@ -107,6 +107,7 @@ void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const f
                     unsigned short (*to_bf16)(float), unsigned short* img, float* b1p);
 hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
+hipError_t launch_mlp_reduce(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t init_mlp_fused_kernels();
 
 struct EmbedArgs {

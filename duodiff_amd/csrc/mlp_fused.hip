@@ -835,12 +835,14 @@ hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     } else {
         hipLaunchKernelGGL((mlp_fused_kernel<D, false, false>), dim3(grid), dim3(256), lds, s, a);
     }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && a.tiles_left > 0) {
-        hipLaunchKernelGGL(mlp_reduce_kernel<D / 64>, dim3((unsigned)((a.n_extra + 3) / 4)), dim3(256), 0, s, a);
-        e = hipGetLastError();
-    }
-    return e;
+    return hipGetLastError();
+}
+
+template <int D>
+hipError_t launch_reduce_d(const MlpFusedArgs& a, hipStream_t s) {
+    if (a.tiles_left <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mlp_reduce_kernel<D / 64>, dim3((unsigned)((a.n_extra + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 
@@ -954,12 +956,22 @@ hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
     return hipGetLastError();
 }
 
+// the fused launch itself; the extra-token rows are finished by launch_mlp_reduce right behind it
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s) {
     switch (D) {
         case 64: return launch_d<64>(a, s);
         case 128: return launch_d<128>(a, s);
         case 256: return launch_d<256>(a, s);
         case 512: return launch_d<512>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_mlp_reduce(const MlpFusedArgs& a, int D, hipStream_t s) {
+    switch (D) {
+        case 64: return launch_reduce_d<64>(a, s);
+        case 128: return launch_reduce_d<128>(a, s);
+        case 256: return launch_reduce_d<256>(a, s);
+        case 512: return launch_reduce_d<512>(a, s);
     }
     return hipErrorInvalidValue;
 }
