@@ -364,7 +364,10 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                         char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
                         [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
                     }
-                    constexpr int gn = g + PDp, left = NGp - 1 - g, LG = left < PDp - 1 ? left : PDp - 1;
+                    // one counted wait per pair of gaps, as in the chunk loop: the even gap waits for the odd gap's fragment too
+                    constexpr int gn = g + PDp, left = NGp - 1 - g;
+                    constexpr int lg_self = left < PDp - 1 ? left : PDp - 1, lg_next = left - 1 < PDp - 1 ? left - 1 : PDp - 1;
+                    constexpr int LG = (g & 1) ? -1 : (left >= 1 ? lg_next - (left >= PDp ? 1 : 0) : lg_self);   // (this gap's own read is not issued yet)
                     constexpr bool RD = gn < NGp;
                     constexpr int LO = RD ? ((gn / C::F) & 3) * C::BLK + (gn % C::F) * 1024 : 0;
                     constexpr int LOA = LO < 65536 ? LO : LO - 65536;
