@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of 1000-step DDPM DuoDiff sampling, CelebA 64x64
-(uvit_celeba_3.yaml shallow for t=999..700 + uvit_celeba.yaml full for t=699..0, t_switch=300),
-batch 128 per GPU, bf16 MFMA operands, synthetic seeded weights and noise.
+"""Headline benchmark: images/sec of 1000-step DDPM DuoDiff sampling on MI355X, bf16 MFMA operands, synthetic seeded
+weights and noise.  Default workload = BASELINE.json's metric: CelebA 64x64 (uvit_celeba_3.yaml shallow for t=999..700 +
+uvit_celeba.yaml full for t=699..0, t_switch=300), batch 128 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload celeba|imagenet64|imagenet256]
+
+With --gpus N > 1 and no torchrun environment the script launches its N ranks ITSELF (child processes with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before this process touches the GPU), relays rank 0's JSON line and exits
+non-zero if any rank does; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one
+rank of that launch.
 
 A "step" is one sampling step (U-ViT forward + fused DDPM update) over the rank's batch.
 K = 1000 (default) is one complete sampling run and `value` is then measured, not extrapolated.
@@ -17,6 +21,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,21 +38,30 @@ from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PROFILE_DIR = REPO / "profiles" / "r03"     # committed rocprofv3 --pmc summaries (tools/collect_pmc.sh), keyed by build id
+
+# BASELINE.json configs[1], [3], [4]: (label, shallow yaml, full yaml, batch per GPU, CPU-baseline sample (images, steps))
+WORKLOADS = {
+    "celeba": ("CelebA-64", "uvit_celeba_3", "uvit_celeba", 128, (16, 30)),
+    "imagenet64": ("ImageNet-64", "uvit_imagenet64_3", "uvit_imagenet64", 256, (8, 20)),
+    "imagenet256": ("ImageNet-256 (32x32x4 latents)", "uvit_imagenet256_3", "uvit_imagenet256", 32, (8, 20)),
+}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1000)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--batch", type=int, default=128, help="images per GPU")
+    p.add_argument("--workload", default="celeba", choices=sorted(WORKLOADS))
+    p.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's BASELINE batch)")
     p.add_argument("--t_switch", type=int, default=300)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no_graph", action="store_true")
     p.add_argument("--no_cpu_baseline", action="store_true")
-    p.add_argument("--cpu_batch", type=int, default=16)
-    p.add_argument("--cpu_steps", type=int, default=30)
-    return p.parse_args()
+    p.add_argument("--cpu_batch", type=int, default=0)
+    p.add_argument("--cpu_steps", type=int, default=0)
+    return p.parse_args(argv)
 
 
 def host_cores():
@@ -61,7 +76,7 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(mp_s, mp_f, sd_s, sd_f, batch, steps, t_switch):
+def cpu_baseline(mp_s, mp_f, sd_s, sd_f, batch, steps, t_switch, y=None):
     """The oracle (CPU port of the reference path) on the host cores, on a bounded sample of the
     same workload: `batch` images, `steps` sampling steps with the 30/70 shallow/full mix."""
     import oracle
@@ -78,7 +93,7 @@ def cpu_baseline(mp_s, mp_f, sd_s, sd_f, batch, steps, t_switch):
     for i in range(steps):
         t = 999 - i
         model = m_s if i < n_shallow else m_f
-        eps = model(x, np.full((batch,), t, np.float32))
+        eps = model(x, np.full((batch,), t, np.float32), y)
         z = torch.randn(x.shape, generator=g).numpy()
         x = oracle.ddpm_step(x, eps, z, t, tables)
     dt = time.perf_counter() - t0
@@ -92,14 +107,61 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def self_launch(a, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as children (one process per GPU, rendezvous on 127.0.0.1), before
+    this process has made any GPU call; relay rank 0's stdout (the JSON line); fail if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(a.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    log(f"launched {a.gpus} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in (out0 or "").splitlines():      # rank 0's JSON line goes to stdout; anything a transport library printed there, to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    return 0
+
+
+def committed_pmc(build_id):
+    """Counter values of the dominant kernel from the committed rocprofv3 --pmc summaries -- only if they were collected
+    on THIS build of the library (the summaries record dd_build_id()); otherwise (None, None, reason)."""
+    try:
+        pmc = json.load(open(PROFILE_DIR / "pmc_traffic.json"))
+        sq = json.load(open(PROFILE_DIR / "pmc_sq.json"))
+    except Exception as e:
+        return None, None, f"no committed PMC profile under {PROFILE_DIR.relative_to(REPO)} ({type(e).__name__})"
+    have = pmc.get("_build_id"), sq.get("_build_id")
+    if have[0] != build_id or have[1] != build_id:
+        return None, None, (f"committed PMC profile is of another build ({have[0]} / {have[1]}, running {build_id}): "
+                            "counters not quoted")
+    try:
+        k = next(v for n, v in pmc.items() if "mlp_fused_kernel" in n)
+        busy = next(v["mfma_busy_frac"] for n, v in sq.items() if "mlp_fused_kernel" in n)
+        return (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6, busy, None
+    except StopIteration:
+        return None, None, "committed PMC profile holds no fused block-tail kernel"
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a, argv)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         "or run bench.py --gpus N without a torchrun environment (it then launches its ranks itself)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -115,24 +177,30 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path (duodiff_amd._lib.EngineUnavailable)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
-    from duodiff_amd import sampler
+    from duodiff_amd import _lib, sampler
     from duodiff_amd.engine import sample_loop
     from duodiff_amd.uvit import UViT
 
-    mp_s = ModelParams.from_dict(load_config(REPO / "configs" / "uvit_celeba_3.yaml"))
-    mp_f = ModelParams.from_dict(load_config(REPO / "configs" / "uvit_celeba.yaml"))
+    label, cfg_s, cfg_f, batch_default, cpu_sample = WORKLOADS[a.workload]
+    B = a.batch or batch_default
+    mp_s = ModelParams.from_dict(load_config(REPO / "configs" / f"{cfg_s}.yaml"))
+    mp_f = ModelParams.from_dict(load_config(REPO / "configs" / f"{cfg_f}.yaml"))
     sd_s, sd_f = synthetic_state_dict(mp_s, 1237), synthetic_state_dict(mp_f, 1236)
     dev = f"cuda:{local_rank}"
-    shallow = UViT(**mp_s.as_dict(), precision=a.precision, max_batch=a.batch).load_state_dict(sd_s).to(dev)
-    full = UViT(**mp_f.as_dict(), precision=a.precision, max_batch=a.batch).load_state_dict(sd_f).to(dev)
-    es, ef = shallow.engine_model(a.batch), full.engine_model(a.batch)
+    shallow = UViT(**mp_s.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_s).to(dev)
+    full = UViT(**mp_f.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_f).to(dev)
+    es, ef = shallow.engine_model(B), full.engine_model(B)
     ctx = es.ctx
+    build_id = _lib.load().dd_build_id().decode()
 
-    B, K, W = a.batch, a.steps, a.warmup
-    log(f"models ready on {dev}; B={B} K={K} W={W}")
+    K, W = a.steps, a.warmup
+    log(f"{label}: models ready on {dev}; B={B} K={K} W={W}; library build {build_id}")
     seed = 0 + rank
     sampler.seed_everything(seed)
     x_T = torch.randn(B, mp_f.in_chans, mp_f.img_size, mp_f.img_size).to(dev).contiguous()
+    y = None
+    if mp_f.num_classes > 0:      # class-conditional workloads: labels as the reference CLI draws them (sampler.py:314-318)
+        y = torch.randint(1, 1001, (B,)).clamp(max=mp_f.num_classes - 1).to(dev)
     stream = torch.cuda.Stream(device=dev)
     use_graph = not a.no_graph
     # K timed steps: t = 999 .. 1000-K, switch after round(t_switch * K / 1000) steps
@@ -141,12 +209,14 @@ def main():
 
     def run(x, n_steps, t_sw, t_stop):
         with torch.cuda.stream(stream):
-            sample_loop(ctx, es, ef, x, t_switch=t_sw, t_start=999, t_end=t_stop, seed=seed, noise="philox",
+            sample_loop(ctx, es, ef, x, t_switch=t_sw, t_start=999, t_end=t_stop, y=y, seed=seed, noise="philox",
                         use_graph=use_graph, stream=stream)
 
     # One timed pass = K sampling steps + the output conversion (x+1)/2 -> NHWC (library kernel, reference
     # sampler.py:145-146) + for N > 1 the single RCCL all_gather of the finished images.  Nothing else runs between
     # t0 and dt: no torch op, no allocation (every buffer below is created before the warm-up).
+    # (ImageNet-256: x is the 32x32x4 latent; the reference decodes it once per run with the KL-VAE -- 2.8 ms / image on this
+    # engine, 1.4 % of a 1000-step latent, DESIGN section 7 -- outside the per-step metric.)
     x = x_T.clone()  # one persistent state buffer: the captured graphs bake its address in
     imgs = torch.empty(B, mp_f.img_size, mp_f.img_size, mp_f.in_chans, device=dev)
     gathered = [torch.empty_like(imgs) for _ in range(world)] if world > 1 else None
@@ -187,10 +257,11 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing = ctx.last_sample_timing()   # hipEvents around the K steps of this rank's dd_sample call
-    t_all = torch.tensor([dt], device=dev if dist is None or dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    on_dev = dist is None or dist.get_backend() == "nccl"
+    t_all = torch.tensor([dt, timing[0]], device=dev if on_dev else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    dt = float(t_all.item())
+    dt, gpu_ms_max = float(t_all[0].item()), float(t_all[1].item())
     log(f"timed region done: {dt:.3f} s")
     finite = bool(torch.isfinite(imgs).all().item())
 
@@ -199,68 +270,78 @@ def main():
         value = images / (dt * 1000.0 / K)
         flop_img = 0.3 * mp_s.flops_per_image() * 1000 + 0.7 * mp_f.flops_per_image() * 1000
         e2e_tflops = value * flop_img / 1e12 / world
-        # Dominant kernel: the fused block-tail launch of the full model's blocks (mlp_fused_kernel: attn.proj + residual +
-        # norm2 + fc1 + bias + exact-erf GELU + fc2 + bias + residual + next norm1, plus its small extra-token launches)
-        # -- 3/4 of a block's Linear FLOPs.  Timed live IN CONTEXT: hipEvent pairs on the launch stream around every such
-        # launch of 20 eager full-model steps run right after the timed region (same buffers, cache and clock state).
+        # Dominant kernel of the full model's blocks, timed live IN CONTEXT: hipEvent pairs on the launch stream around every
+        # such launch of 20 eager full-model steps run right after the timed region (same buffers, cache and clock state).
+        #   D <= 512: the fused block tail (mlp_fused_kernel: attn.proj + residual + norm2 + fc1 + bias + exact-erf GELU + fc2 +
+        #             bias + residual + next norm1 of the PATCH rows; the extra-token rows run in small launches outside the pair)
+        #   else:     the fc1 GEMM (bias + GELU epilogue) of the two-GEMM path
         with torch.cuda.stream(stream):
-            ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, stream=stream)
-        M_rows, D_, H_ = B * mp_f.seq_len, mp_f.embed_dim, 4 * mp_f.embed_dim
-        fl = 2.0 * M_rows * D_ * H_ * 2 + 2.0 * M_rows * D_ * D_      # fc1 + fc2 + attn.proj
+            ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, y=y, stream=stream)
+        D_, H_ = mp_f.embed_dim, 4 * mp_f.embed_dim
+        fused = a.precision == "bf16" and D_ in (64, 128, 256, 512)
+        if fused:
+            M_rows = B * mp_f.seq_len                                  # fc1 + fc2 of every row (the extra-token rows run in the launch's
+            fl = 2.0 * M_rows * D_ * H_ * 2 + 2.0 * B * mp_f.num_patches * D_ * D_   # hidden-split workgroups) + attn.proj of the patch rows
+            # algorithmic bytes of one launch: fp32 residual rows read once and written once, the bf16 attention output read
+            # once, bf16 copy for the long skip, bf16 norm1 output for the next block, the bf16 weights once
+            alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2 + 2) + (2 * D_ * H_ + D_ * D_) * 2
+            kname = ("mlp_fused_kernel<%d>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d "
+                     "(the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (D_, M_rows, D_, H_))
+        else:
+            M_rows = B * mp_f.seq_len
+            fl = 2.0 * M_rows * D_ * H_
+            alg_bytes = M_rows * D_ * 2 + M_rows * H_ * 2 + D_ * H_ * 2
+            kname = "gemm256_kernel<EPI_BIAS_GELU>: fc1 + bias + exact-erf GELU, M=%d K=%d N=%d" % (M_rows, D_, H_)
         ach = fl / (ms * 1e-3) / 1e12
-        # algorithmic bytes of one launch: fp32 residual rows read once and written once, the bf16 attention output read
-        # once, bf16 copy for the long skip, bf16 norm1 output for the next block, the bf16 weights once
-        alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2 + 2) + (2 * D_ * H_ + D_ * D_) * 2
-        # HBM bytes / MFMA-busy fraction of that kernel come from the COMMITTED rocprofv3 --pmc profile of this build
-        # (profiles/r02/pmc_traffic.json, pmc_sq.json; FETCH_SIZE corrected per profiles/r02/fetch_calibration.txt): they are
-        # profile references, not measured in this run -- rocprofv3 cannot run inside this process
-        traffic = None
-        mfma_busy = None
-        try:
-            pmc = json.load(open(REPO / "profiles" / "r02" / "pmc_traffic.json"))
-            k = next(v for n, v in pmc.items() if "mlp_fused_kernel" in n)
-            traffic = (k["fetch_MB_corrected"] + k["write_MB"]) * 1e6
-            sq = json.load(open(REPO / "profiles" / "r02" / "pmc_sq.json"))
-            mfma_busy = next(v["mfma_busy_frac"] for n, v in sq.items() if "mlp_fused_kernel" in n)
-        except Exception:
-            pass
+        # HBM bytes / MFMA-busy fraction of that kernel: quoted from the COMMITTED rocprofv3 --pmc profile only when that profile
+        # was collected on the build that is running (rocprofv3 cannot run inside this process); null + reason otherwise
+        traffic, mfma_busy, why_not = (None, None, "PMC profile is collected for the headline workload only")
+        if a.workload == "celeba" and fused:
+            traffic, mfma_busy, why_not = committed_pmc(build_id)
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
         out = {
-            "metric": "images/sec (whole node) DuoDiff 1000-step CelebA-64",
+            "metric": "images/sec (whole node) DuoDiff 1000-step %s" % label,
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt * 1000.0 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": "CelebA 64x64 DuoDiff: uvit_celeba_3 (t=999..700) + uvit_celeba (t=699..0), "
-                                   "t_switch=300, 1000-step DDPM, batch 128/GPU, device Philox noise",
+            "config": {"workload": "%s DuoDiff: %s (t=999..700) + %s (t=699..0), t_switch=300, 1000-step DDPM, batch %d/GPU, "
+                                   "device Philox noise" % (label, cfg_s, cfg_f, B),
                        "batch_per_gpu": B, "t_switch": a.t_switch, "hipgraph": use_graph,
                        "timed_steps": K, "switch_after_steps": k_switch,
                        "seconds_per_sample": (dt * 1000.0 / K) / images, "finite": finite,
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],
-                       "host_overhead_ms": dt * 1000.0 - timing[0]},
+                       # wall time of the timed region (MAX over ranks) minus the slowest rank's GPU time of the K steps: output kernel,
+                       # the all_gather, barriers, rank skew and host launch overhead together
+                       "non_step_ms": dt * 1000.0 - gpu_ms_max,
+                       "library_build_id": build_id},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "bytes/launch from the committed rocprofv3 --pmc profile profiles/r02/pmc_traffic.json (not measured in this run)",
+                         "traffic_source": (f"bytes/launch from the committed rocprofv3 --pmc profile {PROFILE_DIR.relative_to(REPO)}/pmc_traffic.json, "
+                                            f"collected on this build ({build_id}); not measured in this run") if traffic else why_not,
                          "algorithmic_bytes": alg_bytes,
-                         "kernel": "mlp_fused_kernel<512>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d (the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (M_rows, D_, H_),
+                         "kernel": kname,
                          "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
                          "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
-                         "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": 8000.0,
+                         "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "mfma_busy_frac_pmc": mfma_busy,
-                         "mfma_busy_source": "committed profile profiles/r02/pmc_sq.json (not measured in this run)",
+                         "mfma_busy_source": (f"committed profile {PROFILE_DIR.relative_to(REPO)}/pmc_sq.json of this build; not measured in this run") if mfma_busy else why_not,
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
                                            "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
         }
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(mp_s, mp_f, sd_s, sd_f, a.cpu_batch, a.cpu_steps, a.t_switch)
+            cb, cs = a.cpu_batch or cpu_sample[0], a.cpu_steps or cpu_sample[1]
+            ycpu = y[:cb].cpu().numpy() if y is not None else None
+            out["cpu_baseline"] = cpu_baseline(mp_s, mp_f, sd_s, sd_f, cb, cs, a.t_switch, ycpu)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,6 +34,20 @@ def sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+def source_id(extra_flags=()) -> str:
+    """Build id of the library: hash of every source and header it is compiled from (+ non-default flags).  Exported as
+    dd_build_id(); profiles/rNN/pmc_*.json record it, and bench.py quotes a profile's counters only for the build they
+    were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted([*CSRC.glob("*.hip"), *CSRC.glob("*.h"), *(REPO / "include").glob("*.h")]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    for fl in extra_flags:
+        h.update(fl.encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(out: Path, deps) -> bool:
     if not out.exists():
         return True
@@ -45,15 +59,19 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     OBJ.mkdir(parents=True, exist_ok=True)
     headers = list(CSRC.glob("*.h")) + list((REPO / "include").glob("*.h"))
+    extra = os.environ.get("DD_EXTRA_HIPCC_FLAGS", "").split()
+    bid = source_id(extra)
+    id_file = OBJ / "build_id.txt"
+    id_stale = not id_file.exists() or id_file.read_text().strip() != bid
     jobs = []
     for src in sources():
         obj = OBJ / (src.stem + ".o")
-        if force or _stale(obj, [src, *headers]):
+        if force or _stale(obj, [src, *headers]) or (id_stale and src.stem == "capi"):   # capi.hip carries the id
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [cc, *FLAGS, *os.environ.get("DD_EXTRA_HIPCC_FLAGS", "").split(), "-c", str(src), "-o", str(obj)]
+        cmd = [cc, *FLAGS, *extra, f'-DDD_BUILD_ID="{bid}"', "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,6 +92,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    id_file.write_text(bid + "\n")
     return LIB
 
 

@@ -86,11 +86,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         // two keys per item (K and V rows go in as 16-byte chunks).
         // All loads of the (at most 5) items of a thread are issued BEFORE the first LDS write: written as a plain loop the
         // compiler keeps load -> wait -> write per iteration, i.e. five serial HBM round trips per workgroup.
-#if defined(DD_ATTN_ABLATE) && (DD_ATTN_ABLATE == 2 || DD_ATTN_ABLATE >= 5)     // development builds only (tools/build_variant.py): 2, 5.. = no staging
-        const int items = 0;
-#else
         const int items = nkt * 16 * CPR;
-#endif
         constexpr int ITER = (kMaxKeyTiles * 16 * CPR + 255) / 256;
         f32x4 k0[ITER], k1[ITER], v0[ITER], v1[ITER];
 #pragma unroll
@@ -98,7 +94,6 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             const int idx = tid + it * 256;
             const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
             k0[it] = k1[it] = v0[it] = v1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if !defined(DD_ATTN_ABLATE) || DD_ATTN_ABLATE != 4     // 4 = LDS writes of zeros, no loads
             if (idx < items && key < L) {
                 k0[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
                 v0[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
@@ -107,19 +102,13 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                 k1[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
                 v1[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
             }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * 256;
             const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
-#if defined(DD_ATTN_ABLATE) && DD_ATTN_ABLATE == 3     // 3 = loads only: one LDS write per item keeps them alive
-            if (idx < items) *reinterpret_cast<f32x4*>(Ks + tid * 16) = k0[it] + k1[it] + v0[it] + v1[it];
-            if (false) {
-#else
             if (idx < items) {
-#endif
                 *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0[it];
                 *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1[it];
                 *reinterpret_cast<f32x4*>(Vt + key * Lay::kRowV + ((ch ^ (2 * (key & 3))) << 4)) = v0[it];
@@ -144,9 +133,6 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     }
 
     __syncthreads();
-#if defined(DD_ATTN_ABLATE) && (DD_ATTN_ABLATE == 1 || DD_ATTN_ABLATE >= 3)     // 1 = staging only (3, 4: parts of it)
-    if (Ks[tid] != 77) return;
-#endif
 
     // One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
     // O^T (two 32(d) x 32(q) tiles), the chunk's running max and the sum of exponentials.
@@ -242,12 +228,8 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
                         s[k][e] = 0.f;
                         continue;
                     }
-#if defined(DD_ATTN_ABLATE) && DD_ATTN_ABLATE == 5     // 5 = no exp (a multiply in its place)
-                    p = fmaf(s[k][e], kScaleLog2e, -mxs) * 0.001f;
-#else
                     if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[k][e], kScaleLog2e, -mxs));
                     else p = expf((s[k][e] - mx) * 0.125f);
-#endif
                     s[k][e] = p;
                     sum += p;
                 }
@@ -413,7 +395,8 @@ hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hi
     if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
     using Lay = AttnLayout<T>;
     const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)Lay::kVBytes + kPartBytes;
-    if ((L + 31) / 32 == 9) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
+    // the <T, 9> specialisation assumes L = 256 + 1 or 2 (one or two real keys / queries in the 9th tile): every shipped config
+    if (L == 257 || L == 258) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
     return hipGetLastError();
 }

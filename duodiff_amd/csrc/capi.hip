@@ -42,6 +42,7 @@ struct dd_ctx {
     int64_t* y_stage = nullptr;
     size_t x_stage_elems = 0, y_stage_elems = 0;
     long long graph_captures = 0;
+    unsigned dev_flags = 0;      // dd_dev_set_flags (include/duodiff_dev.h): kernel-variant switches of the development harness
 };
 
 namespace {
@@ -62,9 +63,9 @@ struct BlockW {
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
 
 struct GraphKey {
-    const void* x; const void* y; int B, noise, variance;
+    const void* x; const void* y; int B, noise, variance, num_cus;   // num_cus: the captured persistent grids are sized from it
     bool operator==(const GraphKey& o) const {
-        return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance;
+        return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance && num_cus == o.num_cus;
     }
 };
 
@@ -369,7 +370,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     const int Mp = round_up(M, 256);
     EmbedArgs ea{x_img, m->emb_wt, m->emb_b, m->pos, m->label, (const long long*)y_dev, t_vec, c->st, m->x,
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, D, L, m->extras,
-                 m->cfg.num_classes, m->cfg.normalize_timesteps, Mp};
+                 m->cfg.num_classes, m->cfg.normalize_timesteps, Mp, (c->dev_flags & DD_DEV_GENERIC_EMBED) ? 1 : 0};
     DD_HIP(c, launch_embed(ea, s));
     if (m->tm_w1t) {   // mlp_time_embed: the time token goes through Linear -> SiLU -> Linear (models/uvit.py:264-272, 358)
         TimeMlpArgs ta{m->tm_w1t, m->tm_b1, m->tm_w2t, m->tm_b2, m->pos, t_vec, c->st, m->x, B, D, L, m->extras, m->cfg.normalize_timesteps};
@@ -516,6 +517,11 @@ int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int
 extern "C" {
 
 int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+#ifndef DD_BUILD_ID
+#define DD_BUILD_ID "unknown"
+#endif
+const char* dd_build_id(void) { return DD_BUILD_ID; }
 
 int dd_schedule_table(int which, float* out) {
     if (!out) return DD_ERR_INVALID;
@@ -685,11 +691,9 @@ int dd_model_finalize(dd_model* m, int precision) {
     };
     auto P = [&](const std::string& nm) -> const std::vector<float>& { return m->params[nm].data; };
 
-    // fused MLP (mlp_fused.hip): bf16 mode only; DD_FUSED_MLP=0 keeps the two-GEMM path (A/B runs)
-    const char* env_fused = std::getenv("DD_FUSED_MLP");
-    m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(env_fused && env_fused[0] == '0');
-    const char* env_proj = std::getenv("DD_FUSED_PROJ");
-    m->fused_proj = m->fused_mlp && D % 128 == 0 && !(env_proj && env_proj[0] == '0');
+    // fused block tail (mlp_fused.hip): bf16 mode only (development A/B runs can switch it off: dd_dev_set_flags)
+    m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(c->dev_flags & DD_DEV_NO_FUSED_MLP);
+    m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b; bool skip; };
     std::vector<BlockOff> boffs;
@@ -736,8 +740,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     }
     const size_t o_ng = put_f32(P("norm.weight").data(), D), o_nb = put_f32(P("norm.bias").data(), D);
     // head_dec_kernel operands: the final norm's affine part folded into decoder_pred (dec = Wg . xn + c)
-    const char* env_head = std::getenv("DD_FUSED_HEAD");
-    const bool fused_head = head_dec_supported(D, m->pd) && !(env_head && env_head[0] == '0');
+    const bool fused_head = head_dec_supported(D, m->pd) && !(c->dev_flags & DD_DEV_NO_FUSED_HEAD);
     size_t o_wg = 0, o_dc = 0;
     if (fused_head) {
         const std::vector<float>&wd = P("decoder_pred.weight"), &bd = P("decoder_pred.bias"), &ng = P("norm.weight"), &nbv = P("norm.bias");
@@ -1015,7 +1018,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         y_run = a->y_dev ? c->y_stage : nullptr;
     }
     auto get_graph = [&](dd_model* m) -> int {
-        GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance};
+        GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance, c->num_cus};
         if (m->graph && m->gkey == key) return DD_OK;
         if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         hipGraph_t g = nullptr;
@@ -1060,6 +1063,12 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
 }
 
 long long dd_dev_graph_captures(dd_ctx* c) { return c ? c->graph_captures : -1; }
+
+int dd_dev_set_flags(dd_ctx* c, unsigned flags) {
+    if (!c) return DD_ERR_INVALID;
+    c->dev_flags = flags;
+    return DD_OK;
+}
 
 int dd_last_sample_timing(dd_ctx* c, float out3[3]) {
     if (!c || !out3) return DD_ERR_INVALID;
@@ -1151,7 +1160,7 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     MlpFusedArgs a{};
     if (extras > 0) mlp_fused_plan(M / (1 + extras), 1, extras, 1 + extras, hidden, a);
     else mlp_fused_plan(1, M, 0, M, hidden, a);
-    if (std::getenv("DD_DEV_MLP_EXTRAS_ONLY")) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
+    if (c->dev_flags & DD_DEV_MLP_EXTRAS_ONLY) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
     void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
     void *dAo = nullptr, *dBp = nullptr;

@@ -121,6 +121,7 @@ struct EmbedArgs {
     StepState* st;           // t_model is read, t_final is written (block 0)
     float* x_tok;            // [Mp, D]
     int B, C, S, P, D, L, extras, num_classes, normalize, Mp;
+    int generic;             // != 0: the generic VALU kernel even where the MFMA kernel fits (development A/B runs)
 };
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 

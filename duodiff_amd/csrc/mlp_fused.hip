@@ -175,6 +175,31 @@ __device__ __forceinline__ void acc_pin(f32x16& y) { asm volatile("" : "+a"(y));
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
+// LayerNorm statistics of a row that is spread over the two lane halves (lane, lane ^ 32), D / 2 columns each, from ONE
+// pass over the registers -- without the cancellation of E[x^2] - mean^2: every lane accumulates s = sum(x - c) and
+// q = sum((x - c)^2) around a shift c that is one of its OWN elements (so (mean - c)^2 <= n var and the subtraction
+// q - s^2 / n loses at most ~n eps of var, whatever offset the row carries), and the two halves are combined exactly
+// (Chan et al.).  Both lanes of a row compute bit-identical results.  rstd = 1 / sqrt(var + 1e-5), biased variance
+// (torch.nn.LayerNorm, reference models/uvit.py:185-189).
+template <int D>
+__device__ __forceinline__ void ln_stats_shifted(float c, float s, float q, float& mean, float& rstd) {
+    constexpr float n = (float)(D / 2);
+    const float mh = c + s / n;
+    const float m2h = q - s * s / n;
+    // v_permlane32_swap of a value with itself: afterwards element 0 is the LOWER half's value and element 1 the UPPER
+    // half's, on every lane of the row's pair -- no lane address (a ds_bpermute address computed here would stay live, or
+    // be spilled, across the whole chunk loop for the epilogue's use), and both lanes evaluate the same expression
+    const auto pm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mh), __builtin_bit_cast(unsigned, mh), false, false);
+    const auto p2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2h), __builtin_bit_cast(unsigned, m2h), false, false);
+    const float m_lo = __builtin_bit_cast(float, pm[0]), m_hi = __builtin_bit_cast(float, pm[1]);
+    const float q_lo = __builtin_bit_cast(float, p2[0]), q_hi = __builtin_bit_cast(float, p2[1]);
+    mean = 0.5f * (m_lo + m_hi);
+    const float d = m_lo - m_hi;
+    const float m2 = (q_lo + q_hi) + d * d * (0.5f * n);
+    const float var = m2 / (float)D;
+    rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
+}
+
 template <int D>
 struct MlpCfg {
     static constexpr int NT = D / 32;          // 32-column output tiles of one wave
@@ -300,6 +325,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         // This code runs at one wave per SIMD with nothing to hide latency behind: its length is its cost.
         const float* xr = a.xres + row_pro * D + 4 * h;
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+        float cshift = 0.f;      // shift of the one-pass statistics: the lane's first element (ln_stats_shifted)
         // LA tiles of loads in flight, no more: sched_barrier keeps hipcc from hoisting all 64 loads (256 registers)
         // above the arithmetic (that version spilled); statistics in one pass on register quads (packed fp32 math)
         constexpr int LA = C::NT < 4 ? C::NT : (PARTIAL && C::NT >= 8) ? 8 : 4;   // hidden-split tiles: nothing else is live yet, and the workgroup is pure latency
@@ -328,8 +354,12 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             for (int g = 0; g < 4; ++g) {
                 f32x4 q = xq[t % LA][g];
                 if constexpr (PROJ) q += *reinterpret_cast<const f32x4*>(lbp + 32 * t + 8 * g);   // x + bproj: the projection accumulates on top
-                s4 += q;
-                q4 += q * q;
+                if constexpr (!PROJ) {                     // (PROJ: the statistics are taken from x1 after the projection)
+                    if (t == 0 && g == 0) cshift = q[0];
+                    const f32x4 dq = q - cshift;
+                    s4 += dq;
+                    q4 += dq * dq;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Y[t][4 * g + e] = q[e];
             }
@@ -382,21 +412,19 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             for (int t = 0; t < C::NT; ++t) {
                 acc_pin(Y[t]);
                 const f32x16 yt = Y[t];
+                if (t == 0) cshift = yt[0];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
-                    s4 += q;
-                    q4 += q * q;
+                    const f32x4 dq = q - cshift;
+                    s4 += dq;
+                    q4 += dq * dq;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-        sum += __shfl_xor(sum, 32);
-        sq += __shfl_xor(sq, 32);
-        const float mean = sum / (float)D;
-        const float var = sq / (float)D - mean * mean;
-        const float rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
+        float mean, rstd;
+        ln_stats_shifted<D>(cshift, (s4[0] + s4[1]) + (s4[2] + s4[3]), (q4[0] + q4[1]) + (q4[2] + q4[3]), mean, rstd);
         const float shift = -mean * rstd;
         __syncthreads();   // (vmcnt(0): the MLP's first three blocks have landed; bias table, vectors [and zero block] are visible)
         // k-step ks of fc1 = registers 8 (ks & 1) .. + 7 of tile ks >> 1: element j is column
@@ -519,19 +547,13 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 constexpr int lg_next = PD - 1 + ((g + 1 > KB && g + 1 <= KB + PD) ? 4 : 0);
                 constexpr int LG = (g & 1) ? -1 : lg_next - 1 - (g == KB ? 4 : 0);
                 static_assert(KB % 2 == 0 || C::F < 4, "pair waits assume an even bias gap");
-#if defined(DD_MLP_ABLATE) && DD_MLP_ABLATE == 3      // development builds only (tools/build_variant.py): 3 = no GELU
-                constexpr int K = -1;
-                pw[(g * PPG) >> 3] = 0x3c003c00u;
-#else
                 constexpr int id0 = g * PPG;
                 constexpr int K = PPG == 1 ? (id0 & 7) : -1;
-#endif
                 constexpr int pair = (g * PPG) >> 3;
                 if constexpr (g < C::F)
                     gap_stmt<1, LG, true, LOA, K>(Y[g >> 1], wq[g % PD], p_prev[g & 1], la, s_cur[2 * pair], s_cur[2 * pair + 1], gk, gr, pw[pair]);
                 else
                     gap_stmt<0, LG, true, LOA, K>(s_next, wq[g % PD], xf[g - C::F], la, s_cur[2 * pair], s_cur[2 * pair + 1], gk, gr, pw[pair]);
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 3
                 if constexpr (PPG > 1) {   // D < 512: several GELU pieces per gap, as statements of their own
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         ([&] {
@@ -540,15 +562,12 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                         }(), ...);
                     }(std::make_integer_sequence<int, PPG>{});
                 }
-#endif
                 if constexpr (g == KB) bias_init(c + 1, s_next);
-#if !defined(DD_MLP_ABLATE) || DD_MLP_ABLATE != 1     // 1 = no DMA in the loop
                 if constexpr (g % DSTEP == DSTEP / 2) {
                     constexpr int j = (g % C::F) / DSTEP;
                     if constexpr (g < C::F) glds16u_j<j>(src_e, dma_voff, dst_e);
                     else glds16u_j<j>(src_m, dma_voff, dst_m);
                 }
-#endif
             }(), ...);
         }(std::make_integer_sequence<int, NG>{});
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -558,9 +577,6 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 
     bf16x8 pA[2], pB[2];
     pA[0] = pA[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#if defined(DD_MLP_ABLATE) && DD_MLP_ABLATE == 5      // development builds only: 5 = prologue + tail + epilogue, no chunk loop
-    c1 = c0;
-#endif
     for (int c = c0; c < c1; c += 2) {   // c0 and c1 are even (mlp_fused_plan): no control flow around the accumulators
         iteration(std::integral_constant<int, 0>{}, c, sA, sB, pA, pB);
         iteration(std::integral_constant<int, 1>{}, c + 1, sB, sA, pB, pA);
@@ -609,6 +625,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             for (int g = 0; g < 4; ++g) xl[0][g] = *reinterpret_cast<const f32x4*>(xrow + 8 * g);
         }
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+        float cshift = 0.f;
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             if constexpr (!LNIN) {
@@ -626,8 +643,10 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 if constexpr (!LNIN) q = xl[t & 1][g] + q;
                 *reinterpret_cast<f32x4*>(xrow + 32 * t + 8 * g) = q;
                 v[g] = uint2{pack2(q[0], q[1]), pack2(q[2], q[3])};
-                s4 += q;
-                q4 += q * q;
+                if (t == 0 && g == 0) cshift = q[0];
+                const f32x4 dq = q - cshift;
+                s4 += dq;
+                q4 += dq * dq;
             }
             if (a.out) {
                 // bf16 copy as 16-byte row segments: v_permlane32_swap joins the two lane halves (see gemm.hip)
@@ -639,16 +658,17 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                     *reinterpret_cast<uint4*>(a.out + row * a.ldo + 32 * t + 8 * gp + 8 * he) = o;
                 }
             }
+            acc_pin(Y[t]);                       // the copy dies here: the LayerNorm pass below re-reads the accumulators instead of a spill slot
+            asm volatile("" : "+v"(s4), "+v"(q4));   // the statistics are accumulated HERE (hipcc otherwise sinks them into the ln_out
+                                                     // branch below and keeps -- spills -- all 256 row values for it)
             __builtin_amdgcn_sched_barrier(0);   // tile by tile: keeps the live set small (no spills)
         }
         if (LNIN && a.ln_out) {   // LayerNorm of the updated row (the next block's norm1) as bf16, from the registers (LNIN mode only)
-            float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-            sum += __shfl_xor(sum, 32);
-            sq += __shfl_xor(sq, 32);
-            const float mean = sum / (float)D;
-            const float var = sq / (float)D - mean * mean;
-            const float rstd = 1.0f / sqrtf((var > 0.f ? var : 0.f) + 1e-5f);
+            float mean, rstd;
+            ln_stats_shifted<D>(cshift, (s4[0] + s4[1]) + (s4[2] + s4[3]), (q4[0] + q4[1]) + (q4[2] + q4[3]), mean, rstd);
             const float shift = -mean * rstd;
+            const float* lb2r = lb2;
+            asm volatile("" : "+v"(lb2r));        // a second read of the bias quads from LDS, not 64 values carried over from pass 1 (spills)
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 uint2 v[4];
@@ -657,7 +677,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 for (int g = 0; g < 4; ++g) {
                     // the updated row is rebuilt from the (read-only) accumulators: cheaper than writing it back in pass 1
                     f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
-                    q += *reinterpret_cast<const f32x4*>(lb2 + 32 * t + 8 * g);
+                    q += *reinterpret_cast<const f32x4*>(lb2r + 32 * t + 8 * g);
                     const f32x4 gv = *reinterpret_cast<const f32x4*>(lg_out + 32 * t + 8 * g), bv = *reinterpret_cast<const f32x4*>(lb_out + 32 * t + 8 * g);
                     const f32x4 w = (q * rstd + shift) * gv + bv;
                     v[g] = uint2{pack2(w[0], w[1]), pack2(w[2], w[3])};

@@ -656,8 +656,7 @@ bool embed_mfma_ok(const EmbedArgs& a, size_t& lds) {
 
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     size_t mlds = 0;
-    static const bool no_mfma = [] { const char* e = std::getenv("DD_EMBED_MFMA"); return e && e[0] == '0'; }();
-    if (!no_mfma && embed_mfma_ok(a, mlds)) {
+    if (!a.generic && embed_mfma_ok(a, mlds)) {
         const dim3 grid((unsigned)((a.B * 16 + 7) / 8));
         if (a.P == 4) hipLaunchKernelGGL((embed_mfma_kernel<4, 3>), grid, dim3(512), mlds, s, a);
         else if (a.C == 3) hipLaunchKernelGGL((embed_mfma_kernel<2, 3>), grid, dim3(512), mlds, s, a);

@@ -115,7 +115,7 @@ def main(argv=None):
         y = None
         if args.class_id is not None:
             sampler.seed_everything(seed)
-            y = torch.randint(1, 1001, (args.batch_size,))
+            y = sampler.draw_labels(args.batch_size, mp.num_classes)      # same range check as the single-GPU CLI
         s, _ = sampler.get_samples(model, args.batch_size, post, seed, mp.in_chans, mp.img_size, mp.img_size,
                                    use_ddim=args.use_ddim, ddim_steps=args.ddim_steps, ddim_eta=args.ddim_eta,
                                    timesteps_save=[], y=y, autoencoder=autoencoder, late_model=late, t_switch=args.t_switch,

@@ -219,6 +219,15 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     return samples.cpu().numpy(), inter                                      # :155 (D2H boundary)
 
 
+def draw_labels(batch_size: int, num_classes: int):
+    """reference sampler.py:314-318: labels are randint(1, 1001) whatever --class_id says (quirk Q4); a label the embedding
+    table does not hold raises the IndexError nn.Embedding raises there (the engine would read past label_emb)."""
+    y = torch.randint(1, 1001, (batch_size,))
+    if int(y.max()) >= num_classes or int(y.min()) < 0:
+        raise IndexError("index out of range in self")
+    return y
+
+
 def dump_samples(samples, output_folder: Path, timestep=1000):
     """reference sampler.py:158-184: per-image PNG + grid, values clipped to [0, 1]."""
     from matplotlib import pyplot as plt
@@ -302,10 +311,7 @@ def main(argv=None):
     seed_everything(args.seed)
     y = None
     if args.class_id is not None:
-        # reference sampler.py:314-318: labels are randint(1, 1001), the flag's value is unused (quirk Q4)
-        y = torch.randint(1, 1001, (args.batch_size,))
-        if int(y.max()) >= mp.num_classes:
-            raise IndexError("index out of range in self")
+        y = draw_labels(args.batch_size, mp.num_classes)
     autoencoder = None
     if "autoencoder" in config:                                              # reference sampler.py:320-325
         ae_path = args.autoencoder_checkpoint_path or config["autoencoder"]["autoencoder_checkpoint_path"]

@@ -75,6 +75,9 @@ enum { DD_NOISE_NONE = 0, DD_NOISE_BUFFER = 1, DD_NOISE_PHILOX = 2 };
 
 /* ---- context ---------------------------------------------------------------------- */
 int dd_abi_version(void);
+/* Hash of the sources this library was built from (duodiff_amd/build.py source_id): profile summaries record it, so a
+ * counter value is only ever quoted for the build it was measured on.  Static string; needs no GPU. */
+const char* dd_build_id(void);
 int dd_ctx_create(int device, dd_ctx** out);
 void dd_ctx_destroy(dd_ctx* ctx);
 const char* dd_last_error(dd_ctx* ctx);            /* valid until the next call on ctx */
@@ -204,9 +207,10 @@ void dd_vae_destroy(dd_vae* v);
 int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
                   float* ms_out, double* flops_out);
 /* In-context timing of the dominant kernel: runs `steps` eager sampling steps (t = t_start, t_start-1, ...) in place
- * on x_dev with a hipEvent pair recorded on `stream` around EVERY launch of the block's MLP (depth per step) -- the fused
- * MLP kernel (norm2 + fc1 + GELU + fc2 + residual + next norm1, incl. its small reduce launch) where the model uses it,
- * else the fc1 GEMM -- and returns the average milliseconds per launch: what rocprofv3 --kernel-trace averages. */
+ * on x_dev with a hipEvent pair recorded on `stream` around EVERY launch of the block's dominant kernel (depth per step)
+ * -- the fused block-tail kernel alone (attn.proj + norm2 + fc1 + GELU + fc2 + residual + next norm1 of the patch rows;
+ * the small extra-token launches before and after it are OUTSIDE the pair) where the model uses it, else the fc1 GEMM --
+ * and returns the average milliseconds per launch: what rocprofv3 --kernel-trace averages for that kernel. */
 int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
                      void* stream, float* fc1_ms_out, int* launches_out);
 
@@ -217,7 +221,9 @@ int dd_plan_rows(int M, int N, int K, int num_cus, int* q_out, int* e_out);
 
 /* Number of CUs this context's persistent GEMM grids are sized for (default: the device's CU count, rounded down to
  * a multiple of 8; any value is rounded likewise).  For callers that run the engine on a CU-masked stream
- * (hipExtStreamCreateWithCUMask). */
+ * (hipExtStreamCreateWithCUMask).  Graphs captured by dd_sample are keyed on the value: the next dd_sample re-captures.
+ * A context (its step state, staging buffers and model workspaces) serves ONE stream at a time: calls on different
+ * streams must be ordered by the caller. */
 int dd_set_num_cus(dd_ctx* ctx, int num_cus);
 
 /* Per-step timing of the last dd_sample call, measured with hipEvents on its stream:

@@ -14,7 +14,8 @@ extern "C" {
 /* Development harness for the fused MLP kernel: x += fc2(gelu(fc1(bf16(h)) + b1)) + b2 on host arrays (h [M,D], nn.Linear
  * weights fp32, xres_host [M,D] in/out, out_host optional bf16 copy), plus `iters` timed launches.  extras == 0: the
  * rows are one image of M patch tokens; extras > 0: M / (1 + extras) images of `extras` extra tokens + 1 patch token.
- * ln_in [2, D] (gamma, beta) or NULL: the kernel's fused-LayerNorm prologue is used, h = LayerNorm(xres) (h_host ignored);
+ * ln_in [2, D] (gamma, beta): the kernel's fused-LayerNorm prologue computes h = LayerNorm(xres) itself (h_host is ignored);
+ * ln_in NULL: h_host is the (already normalised) input;
  * ln_out [2, D] + ln_out_host [M, D] bf16 or NULL: LayerNorm of the updated rows from the epilogue.
  * ao_host [M, D] + wproj [D, D] + bproj [D] or NULL (needs ln_in, D % 128 == 0): the attention projection
  * x += ao . wproj^T + bproj runs in front of the MLP in the same launch (extra-token rows: the small kernel the model
@@ -23,6 +24,16 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
                const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
                const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out,
                const float* ao_host, const float* wproj, const float* bproj);
+
+/* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
+ * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
+ * reads no environment variable. */
+#define DD_DEV_NO_FUSED_MLP 1u      /* keep the fc1 / fc2 GEMM pair + LayerNorm launches instead of the fused block tail */
+#define DD_DEV_NO_FUSED_PROJ 2u     /* keep attn.proj as its own GEMM */
+#define DD_DEV_NO_FUSED_HEAD 4u     /* keep final LayerNorm + decoder_pred as two launches */
+#define DD_DEV_GENERIC_EMBED 8u     /* generic VALU patch-embed kernel */
+#define DD_DEV_MLP_EXTRAS_ONLY 16u  /* dd_dev_mlp: launch the hidden-split (extra-token) workgroups alone */
+int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
 
 /* Number of hipGraph captures dd_sample has made on this context so far (tests: a second call with other tensors of the
  * same shape must not capture again). */

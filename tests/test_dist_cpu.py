@@ -97,7 +97,24 @@ def test_bench_launch_plumbing_reaches_the_process_group(tmp_path):
         assert f"process group initialised: rank {rank} of world 2, backend gloo" in se, se[-2000:]
         if not torch.cuda.is_available():
             assert p.returncode != 0 and "no CPU path" in se          # loud failure, no silent fallback
-    # a world/--gpus mismatch is refused before anything else happens
+
+
+def test_bench_self_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun -- the shape of the driver's single-process command -- starts its two ranks
+    itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for each child), waits for them and fails if a rank fails.  Without a
+    GPU both children rendezvous over gloo and then stop loudly at the engine; the parent must report exactly that."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DUODIFF_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"], cwd=str(REPO),
+                       capture_output=True, text=True, env=env, timeout=600)
+    for rank in range(2):
+        assert f"process group initialised: rank {rank} of world 2, backend gloo" in r.stderr, r.stderr[-3000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "ranks failed" in r.stderr and "no CPU path" in r.stderr
+        assert not any(l.lstrip().startswith("{") for l in r.stdout.splitlines())   # no JSON line from a failed run
+    # under torchrun (WORLD_SIZE set) a --gpus mismatch is still refused before anything else happens
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"], cwd=str(REPO), capture_output=True, text=True,
-                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, timeout=300)
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+                       env=env1, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

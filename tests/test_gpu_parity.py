@@ -5,8 +5,10 @@ Tolerances (stated per SURVEY section 7.3 H3 / BASELINE north_star "1e-3 max-abs
   fp32 mode  (f32 MFMA, exact fp32 products): eps within 1e-4 of the reference (observed ~1e-5)
   bf16 mode  (bf16 MFMA operands, fp32 accumulate / residual / LN / softmax):
              one sampling step x_{t-1} within 1e-3 of the reference (teacher-forced);
-             eps itself within 4e-2 max-abs at |eps| ~ 0.5 (the reference's own bf16 autocast
-             misses 1e-3 on eps too: 8.4e-3) -- reported, not hidden.
+             eps itself within 3e-2 * std(eps) max-abs (observed 1.6 - 2.7e-2 * std; the reference's own bf16
+             autocast misses 1e-3 on eps too: 8.4e-3, SURVEY H3) -- reported, not hidden;
+             the benchmarked path (dd_sample, hipGraph replay, CelebA pair, B = 128) free-running for K = 1, 10, 100
+             steps against the fp32 engine: test_benchmarked_path_drift_bf16_vs_fp32.
 """
 import numpy as np
 import pytest
@@ -19,8 +21,12 @@ from duodiff_amd.weights import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 
-EPS_TOL = {"fp32": 1e-4, "bf16": 4e-2}
 STEP_TOL = 1e-3
+
+
+def eps_tol(precision, ref):
+    """max-abs bound on eps: absolute in the exact-fp32 mode, relative to the spread of the reference output in bf16 mode."""
+    return 1e-4 if precision == "fp32" else 3e-2 * float(np.asarray(ref, np.float64).std())
 
 
 def _uvit(cfg, seed, precision, max_batch=None):
@@ -51,8 +57,8 @@ def test_forward_tiny_vs_reference(golden, name, precision):
     y = torch.from_numpy(fx["y"]) if "y" in fx.files else None
     eps = m(torch.from_numpy(fx["x"]), torch.from_numpy(fx["t"]), y).cpu().numpy()
     err = np.abs(eps - fx["eps"]).max()
-    print(f"tiny {name} {precision}: max|eps - ref| = {err:.3e}")
-    assert err <= EPS_TOL[precision]
+    print(f"tiny {name} {precision}: max|eps - ref| = {err:.3e} (std {fx['eps'].std():.3f})")
+    assert err <= eps_tol(precision, fx["eps"])
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -69,7 +75,7 @@ def test_forward_full_size_vs_reference(golden, name, precision):
     err = np.abs(eps[:, :, :16, :16] - fx["eps_slice"]).max()
     st = fx["stats"]
     print(f"{name} {precision}: max|eps - ref| (slice) = {err:.3e}; std {eps.std():.4f} vs {st[1]:.4f}")
-    assert err <= EPS_TOL[precision]
+    assert err <= eps_tol(precision, fx["eps_slice"])
     assert abs(eps.std(dtype=np.float64) - st[1]) <= (1e-4 if precision == "fp32" else 5e-3)
     assert abs(eps.astype(np.float64).sum() - float(fx["checksum"])) <= (1e-5 if precision == "fp32" else 2e-3) * eps.size
 
@@ -241,8 +247,47 @@ def test_full_size_bf16_close_to_fp32_at_batch_128():
     mf, _ = _uvit(cfg, 1236, "fp32", max_batch=128)
     ef = mf(x, t)
     err = (eb - ef).abs().max().item()
-    print(f"celeba B=128: max|eps_bf16 - eps_fp32| = {err:.3e}, rms {((eb - ef) ** 2).mean().sqrt().item():.3e}")
-    assert err <= EPS_TOL["bf16"]
+    rms, sd = ((eb - ef) ** 2).mean().sqrt().item(), ef.std().item()
+    print(f"celeba B=128: max|eps_bf16 - eps_fp32| = {err:.3e}, rms {rms:.3e} (std {sd:.3f})")
+    assert err <= 4e-2 * sd and rms <= 8e-3 * sd      # the maximum over 1.6 M values (the 3e-2 * std bound is stated on 1.5 k-value slices)
+
+
+# observed on MI355X (profiles/r03/parity_numbers.txt) x 1.2: free-running drift of the bf16 product against the fp32 engine,
+# normalised by rms(x): K -> (max, rms)
+DRIFT_BOUND = {1: (4.0e-4, 8.0e-5), 10: (3.0e-3, 6.0e-4), 100: (1.2e-2, 2.5e-3)}
+
+
+@pytest.mark.parametrize("K", [1, 10, 100])
+def test_benchmarked_path_drift_bf16_vs_fp32(K):
+    """The thing bench.py times -- dd_sample, one hipGraph per backbone replayed, CelebA shallow + full pair, B = 128, device
+    Philox noise, the 30 / 70 shallow / full mix -- free-running for K steps in bf16 against the SAME loop on the exact-fp32
+    engine (same x_T, same Philox seed => identical noise): the north_star's "1e-3 max-abs" question asked of the product
+    path itself.  (The fp32 engine is pinned to the oracle / the reference's own rollouts by the tests above.)"""
+    from duodiff_amd.engine import sample_loop
+    B = 128
+    cfg_s, cfg_f = load_config(REPO / "configs" / "uvit_celeba_3.yaml"), load_config(REPO / "configs" / "uvit_celeba.yaml")
+    x_T = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(77)).cuda().contiguous()
+    k_switch = max(1, round(0.3 * K))
+    out = {}
+    for prec in ("bf16", "fp32"):
+        ms, _ = _uvit(cfg_s, 1237, prec, max_batch=B)
+        mf, _ = _uvit(cfg_f, 1236, prec, max_batch=B)
+        es, ef = ms.engine_model(B), mf.engine_model(B)
+        x = x_T.clone()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            sample_loop(es.ctx, es, ef, x, t_switch=k_switch, t_start=999, t_end=1000 - K, seed=5, noise="philox",
+                        use_graph=True, stream=stream)
+        stream.synchronize()
+        out[prec] = x.cpu().numpy().astype(np.float64)
+        del ms, mf, es, ef
+    assert np.isfinite(out["bf16"]).all() and np.isfinite(out["fp32"]).all()
+    scale = float(np.sqrt((out["fp32"] ** 2).mean()))
+    d = np.abs(out["bf16"] - out["fp32"]) / scale
+    dmax, drms = float(d.max()), float(np.sqrt((d ** 2).mean()))
+    print(f"benchmarked path K={K} ({k_switch} shallow + {K - k_switch} full steps, B={B}): bf16 vs fp32 engine max {dmax:.3e} rms {drms:.3e} (rms x {scale:.3f})")
+    assert dmax <= DRIFT_BOUND[K][0] and drms <= DRIFT_BOUND[K][1]
 
 
 def test_error_behaviour_matches_reference_classes():
@@ -340,7 +385,7 @@ def test_ragged_batch_sizes_row_partition(B):
     assert np.isfinite(eps).all()
     for i in sorted({0, B - 1}):
         want = orc(x[i:i + 1].numpy(), np.full((1,), 321.0, np.float32))
-        assert np.abs(eps[i:i + 1] - want).max() <= EPS_TOL["bf16"]
+        assert np.abs(eps[i:i + 1] - want).max() <= eps_tol("bf16", want) * 4 / 3     # (whole image: 12 k values)
         alone = m(x[i:i + 1].contiguous(), t[:1]).cpu().numpy()
         assert np.array_equal(alone, eps[i:i + 1])
 
@@ -357,8 +402,8 @@ def test_conditional_model_full_size_labels():
     eps = m(x, t, y).cpu().numpy()
     want = orc(x.numpy(), t.numpy(), y.numpy())
     err = np.abs(eps - want).max()
-    print(f"imagenet64_3 cond B=6: max|eps - oracle| = {err:.3e}")
-    assert err <= EPS_TOL["bf16"]
+    print(f"imagenet64_3 cond B=6: max|eps - oracle| = {err:.3e} (std {want.std():.3f})")
+    assert err <= eps_tol("bf16", want) * 4 / 3       # (six whole images)
     # a different label changes that image's output and only that image's
     y2 = y.clone(); y2[2] = 501
     eps2 = m(x, t, y2).cpu().numpy()
@@ -494,7 +539,7 @@ def test_full_batch_vs_oracle(name, B):
         want = orc(x[i:i + 1].numpy(), np.full((1,), 250.0, np.float32), y[i:i + 1].numpy() if y is not None else None)
         err = np.abs(eps[i:i + 1] - want).max()
         print(f"{name} B={B} image {i}: max|eps - oracle| = {err:.3e} (std {want.std():.3f})")
-        assert err <= EPS_TOL["bf16"]
+        assert err <= eps_tol("bf16", want) * 4 / 3   # (a whole image)
 
 
 def test_two_ranks_equal_two_single_rank_runs(tmp_path):

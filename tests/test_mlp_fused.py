@@ -78,6 +78,58 @@ def test_fused_mlp_against_float64_reference(M, D, extras, ln, proj):
         assert np.abs(as_f32(hout) - _layernorm(got, ln_out)).max() <= 4e-2
 
 
+@pytest.mark.parametrize("offset,sigma", [(100.0, 1.0), (50.0, 0.5), (-1000.0, 2.0)])
+@pytest.mark.parametrize("proj", [False, True])
+def test_fused_layernorms_on_rows_with_a_large_common_offset(offset, sigma, proj):
+    """Rows whose mean is far larger than their spread (a DC component in the residual stream): the one-pass form
+    E[x^2] - mean^2 loses the variance to cancellation there.  The kernel's shifted statistics (ln_stats_shifted) must keep
+    both fused LayerNorms -- norm2 in the prologue (seen through the MLP output) and the next norm1 from the epilogue --
+    at bf16-rounding accuracy, as the two-pass kernels of the unfused path are (torch.nn.LayerNorm, models/uvit.py:185-189)."""
+    from duodiff_amd.engine import Context
+    ctx = Context.get()
+    M, D, extras = 385, 512, 0
+    hidden = 4 * D
+    g = np.random.default_rng(int(abs(offset)) + int(proj))
+    w1 = (g.standard_normal((hidden, D), dtype=np.float32) * 0.05).astype(np.float32)
+    b1 = (g.standard_normal(hidden, dtype=np.float32) * 0.2).astype(np.float32)
+    w2 = (g.standard_normal((D, hidden), dtype=np.float32) * 0.05).astype(np.float32)
+    b2 = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x = (g.standard_normal((M, D), dtype=np.float32) * sigma + offset).astype(np.float32)
+    x[::7] += np.float32(3 * offset)                   # and the offset differs from row to row
+    ln_in = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ln_out = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ao = g.standard_normal((M, D), dtype=np.float32)
+    wp = (g.standard_normal((D, D), dtype=np.float32) * 0.05).astype(np.float32)
+    bp = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x1 = x
+    if proj:
+        x1 = (x.astype(np.float64) + _bf16(ao).astype(np.float64) @ _bf16(wp).astype(np.float64).T + bp.astype(np.float64)).astype(np.float32)
+    h = _layernorm(x1, ln_in)
+    want = _reference(h, w1, b1, w2, b2, x1)
+    got, out, hout = x.copy(), np.zeros((M, D), np.uint16), np.zeros((M, D), np.uint16)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    ms = C.c_float(0)
+    ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
+                                 P(ln_in), P(ln_out), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
+                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None))
+    contrib = want - x1.astype(np.float64)             # the MLP's contribution, O(1), on top of rows of size |offset|
+    scale = float(contrib.std())
+    ulp = float(np.spacing(np.float32(4 * abs(offset))))   # fp32 resolution of the stored rows
+    err = np.abs((got.astype(np.float64) - x1.astype(np.float64)) - contrib)
+    rms = float(np.sqrt((err ** 2).mean()))
+    as_f32 = lambda u: torch.from_numpy(u.view(np.int16)).view(torch.bfloat16).to(torch.float32).numpy()
+    herr = np.abs(as_f32(hout).astype(np.float64) - _layernorm(got, ln_out).astype(np.float64))
+    hrms = float(np.sqrt((herr ** 2).mean()))
+    print(f"offset={offset} sigma={sigma} proj={proj}: mlp max {err.max():.2e} rms {rms:.2e} (std {scale:.3f}, ulp {ulp:.1e}); "
+          f"ln_out max {herr.max():.2e} rms {hrms:.2e}")
+    assert np.isfinite(got).all()
+    # same bounds as the zero-offset cases (+ the fp32 resolution of the rows themselves)
+    # (a row of size 4000 takes 128 MFMA accumulation steps of the MLP output in fp32: a few ulp of random walk)
+    assert err.max() <= 1.5e-2 * max(scale, 0.1) + 16 * ulp and rms <= 2e-3 * max(scale, 0.1) + 4 * ulp
+    # next norm1: bf16 rounding of values of size <= ~4 (2^-8 * 4 = 1.6e-2 max, ~1e-3 rms); a variance off by 1 % would show as 1e-2 rms
+    assert herr.max() <= 2.5e-2 and hrms <= 2.5e-3
+
+
 def test_fused_mlp_rows_do_not_depend_on_their_neighbours():
     """Which path a row takes (main tile / hidden-split) depends only on its token index, so the same row inside two
     different batches gives bit-identical results (the engine-level statement: test_batch_independence_at_full_size)."""

@@ -19,7 +19,10 @@ from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
 
 
 def build(mp, sd, fused, max_batch):
-    os.environ["DD_FUSED_MLP"] = "1" if fused else "0"
+    from duodiff_amd import _lib
+    from duodiff_amd.engine import Context
+    ctx = Context.get()
+    ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0 if fused else _lib.DD_DEV_NO_FUSED_MLP))
     m = UViT(**mp.as_dict(), precision="bf16", max_batch=max_batch).load_state_dict(sd).to("cuda")
     m.engine_model(max_batch)
     return m

@@ -61,4 +61,8 @@ for k, c in sorted(acc.items(), key=lambda kv: -upper_mean(kv[1].get("SQ_WAVE_CY
     print(f"{k[:60]:60s} {waves:7.0f} {wave_clk:9.0f} {mfma_clk:9.0f} {row['mfma_busy_frac']:9.2f} {row['wait_any']:8.2f} {row['wait_inst']:9.2f} "
           f"{row['active']:7.2f} {(lc if lc is not None else float('nan')):8.3f} {(row['avg_us_under_pmc'] or 0):8.1f}")
 if len(sys.argv) > 2:
+    # the build the counters were collected on (bench.py quotes them only for that build)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from duodiff_amd import _lib
+    out["_build_id"] = _lib.load().dd_build_id().decode()
     json.dump(out, open(sys.argv[2], "w"), indent=1)

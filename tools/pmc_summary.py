@@ -23,4 +23,9 @@ for k in sorted(F, key=lambda k: -sum(v for v, _ in F[k])):
     write_mb = (sum(wm)/len(wm)) * 1024 / 1e6
     out[k] = dict(calls=len(f), fetch_MB_corrected=fetch_mb, write_MB=write_mb, avg_us=sum(t)/len(t)/1e3)
     print(f"{k[:64]:64s} {len(f):6d} {fetch_mb:20.1f} {write_mb:10.1f} {sum(t)/len(t)/1e3:8.1f}")
-json.dump(out, open(sys.argv[3], "w"), indent=1) if len(sys.argv) > 3 else None
+if len(sys.argv) > 3:
+    # the build the counters were collected on (bench.py quotes them only for that build)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from duodiff_amd import _lib
+    out["_build_id"] = _lib.load().dd_build_id().decode()
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
