@@ -29,6 +29,20 @@ class dd_sample_args(C.Structure):
                 ("y_dev", C.c_void_p), ("x_dev", C.c_void_p), ("B", C.c_int32), ("reserved", C.c_int32)]
 
 
+class dd_affine_sample_args(C.Structure):
+    _fields_ = [("first", C.c_void_p), ("late", C.c_void_p), ("n_steps", C.c_int32), ("switch_after", C.c_int32),
+                ("t", C.POINTER(C.c_float)), ("a", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
+                ("c", C.POINTER(C.c_float)), ("noise", C.POINTER(C.c_int32)), ("noise_mode", C.c_int32),
+                ("use_graph", C.c_int32), ("seed", C.c_uint64), ("y_dev", C.c_void_p), ("x_dev", C.c_void_p),
+                ("B", C.c_int32), ("reserved", C.c_int32)]
+
+
+class dd_ee_sample_args(C.Structure):
+    _fields_ = [("model", C.c_void_p), ("threshold", C.c_float), ("t_start", C.c_int32), ("t_end", C.c_int32),
+                ("noise_mode", C.c_int32), ("use_graph", C.c_int32), ("B", C.c_int32), ("seed", C.c_uint64),
+                ("y_dev", C.c_void_p), ("x_dev", C.c_void_p), ("err_dev", C.c_void_p), ("idx_dev", C.c_void_p)]
+
+
 # every symbol include/duodiff.h (and include/duodiff_dev.h: dd_dev_*) declares: name -> (restype, argtypes)
 SIGNATURES = {
     "dd_abi_version": (C.c_int, []),
@@ -59,6 +73,8 @@ SIGNATURES = {
                                  C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dd_to_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dd_sample": (C.c_int, [C.c_void_p, C.POINTER(dd_sample_args), C.c_void_p]),
+    "dd_sample_affine": (C.c_int, [C.c_void_p, C.POINTER(dd_affine_sample_args), C.c_void_p]),
+    "dd_sample_early_exit": (C.c_int, [C.c_void_p, C.POINTER(dd_ee_sample_args), C.c_void_p]),
     "dd_bench_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "dd_vae_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dd_vae_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -3,7 +3,10 @@
 // reference models/uvit.py:155-164: q,k,v = split(qkv) ; softmax(q k^T / sqrt(64)) v per (b, h),
 // fp32 softmax, no mask, heads merged back as "B H L D -> B L (H D)".
 //
-// One workgroup = one (image, head).  K ([L,64], row-major, padded rows) and V^T ([64,L]) of
+// Input: the qkv Linear's output in HEAD-MAJOR order (dd_internal.h HeadMajor: the q, k and v rows of one (image, head) are
+// Lp contiguous 128-byte rows each), so a workgroup's K and V are two linear 33 KB reads -- staged by LDS-DMA in bf16 mode
+// (no registers, 17 instructions per wave) -- instead of 128-byte pieces at a 3 KB stride.
+// One workgroup = one (image, head).  K ([L,64], row-major) and V of
 // the head live in LDS for the whole kernel; every wave takes 32-query chunks:
 //   S^T[key, q] = K . Q^T        (MFMA A = K rows from LDS, B = Q fragment straight from HBM)
 //   softmax over keys            = over accumulator registers (+ one 32-lane exchange): the key
@@ -32,9 +35,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 template <typename T> struct AttnLayout;
 template <> struct AttnLayout<bf16_t> {
-    static constexpr int kRowK = 128 + 16;        // K row: 64 bf16 + 16 B pad  (36 dwords: b128 reads conflict-free)
-    // V stays ROW-major ([key][64 d], 128-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ 2 (r & 3)): staged with
-    // plain 16-byte LDS writes, and read as the V^T MFMA operand with the transposing ds_read_b64_tr_b16 (a block of 4 keys x
+    // K rows are 128 B, LDS-DMA'd linearly (a 1 KB piece = 8 rows); 16-byte chunk ch of row r sits at slot ch ^ ((r >> 1) & 7)
+    // (the swizzle is applied to the SOURCE address of the DMA and again on the read: conflict-free ds_read_b128 fragments,
+    // the same image gemm.hip uses)
+    static constexpr int kRowK = 128;
+    // V stays ROW-major ([key][64 d], 128-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ 2 (r & 3)): LDS-DMA'd like
+    // K, and read as the V^T MFMA operand with the transposing ds_read_b64_tr_b16 (a block of 4 keys x
     // 16 d per 16 lanes; the XOR puts the four rows of a block into the four bank quarters: conflict-free).  The first
     // version wrote V transposed with 4-byte scattered LDS writes -- 12 of the kernel's 47 us.
     static constexpr int kRowV = 128;
@@ -51,7 +57,7 @@ template <> struct AttnLayout<float> {
 // 16 registers and takes ~1000 SGPR-spill lane moves out of the chunk body.  NKT == 0: generic L <= 288.
 template <typename T, int NKT>
 __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1)
-attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, int H, int D) {
+attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, int H, int D, int Lp) {
     using Lay = AttnLayout<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                   // [kLP][kRowK]
@@ -60,10 +66,11 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     const int b = blockIdx.x / H, hh = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, r32 = lane & 31;
-    const long long ld = 3LL * D;
-    const T* qbase = qkv + (long long)b * L * ld + hh * kHD;
-    const T* kbase = qbase + D;
-    const T* vbase = qbase + 2 * D;
+    constexpr long long ld = kHD;                                       // head-major: rows of one unit are contiguous
+    const long long unit = (long long)Lp * kHD;                        // elements per (q | k | v, head) unit
+    const T* qbase = qkv + ((long long)b * 3 * H + hh) * unit;
+    const T* kbase = qbase + (long long)H * unit;
+    const T* vbase = kbase + (long long)H * unit;
     const int nkt = NKT > 0 ? NKT : (L + 31) / 32;     // key tiles actually used
     constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte chunk
     constexpr int CPR = kHD / EPC;                     // chunks per row (8 bf16 / 16 fp32)
@@ -83,38 +90,32 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
     // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
     if constexpr (sizeof(T) == 2) {
-        // two keys per item (K and V rows go in as 16-byte chunks).
-        // All loads of the (at most 5) items of a thread are issued BEFORE the first LDS write: written as a plain loop the
-        // compiler keeps load -> wait -> write per iteration, i.e. five serial HBM round trips per workgroup.
-        const int items = nkt * 16 * CPR;
-        constexpr int ITER = (kMaxKeyTiles * 16 * CPR + 255) / 256;
-        f32x4 k0[ITER], k1[ITER], v0[ITER], v1[ITER];
+        // LDS-DMA, 1 KB pieces of 8 rows x 128 B: piece p of K, then piece p of V; lane = (row 8p + (lane >> 3), slot lane & 7)
+        // fetches the chunk that belongs in its slot (source-side swizzle).  Rows [L, Lp) of the unit are zeros in HBM (never
+        // written); rows [Lp, 32 nkt) of the LDS images are zeroed here (V: 0 x garbage must not be NaN).
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int np = Lp >> 3;                                        // pieces per operand (33 for L = 257 / 258)
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int lr = lane >> 3, slot = lane & 7;
+        constexpr int MAXP = (kLP / 8 * 2 + 3) / 4;                    // pieces per wave, at most
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * 256;
-            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
-            k0[it] = k1[it] = v0[it] = v1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < items && key < L) {
-                k0[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)key * ld + ch * EPC);
-                v0[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)key * ld + ch * EPC);
-            }
-            if (idx < items && key + 1 < L) {
-                k1[it] = *reinterpret_cast<const f32x4*>(kbase + (long long)(key + 1) * ld + ch * EPC);
-                v1[it] = *reinterpret_cast<const f32x4*>(vbase + (long long)(key + 1) * ld + ch * EPC);
+        for (int i = 0; i < MAXP; ++i) {
+            const int p2 = wv + 4 * i;                                 // wave-uniform: [0, np) = K pieces, [np, 2 np) = V pieces
+            if (p2 < 2 * np) {
+                const bool isv = p2 >= np;
+                const int p = isv ? p2 - np : p2, r = 8 * p + lr;
+                const int ch = isv ? (slot ^ (2 * (r & 3))) : (slot ^ ((r >> 1) & 7));
+                const T* src = (isv ? vbase : kbase) + (long long)r * kHD + ch * 8;
+                char* dst = (isv ? Vt : Ks) + p * 1024;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * 256;
-            const int kp = idx / CPR, ch = idx % CPR, key = 2 * kp;
-            if (idx < items) {
-                *reinterpret_cast<f32x4*>(Ks + key * Lay::kRowK + ch * 16) = k0[it];
-                *reinterpret_cast<f32x4*>(Ks + (key + 1) * Lay::kRowK + ch * 16) = k1[it];
-                *reinterpret_cast<f32x4*>(Vt + key * Lay::kRowV + ((ch ^ (2 * (key & 3))) << 4)) = v0[it];
-                *reinterpret_cast<f32x4*>(Vt + (key + 1) * Lay::kRowV + ((ch ^ (2 * ((key + 1) & 3))) << 4)) = v1[it];
-            }
+        for (int i = tid; i < (nkt * 32 - Lp) * 16; i += 256) {       // 8 chunks per row, K and V
+            const int rr = Lp + (i >> 4), c = i & 15;
+            *reinterpret_cast<f32x4*>((c < 8 ? Ks : Vt) + rr * 128 + (c & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces have landed (hipcc does not track LDS-DMA writes)
     } else {
         for (int idx = tid; idx < nkt * 32 * CPR; idx += 256) {
             const int key = idx / CPR, ch = idx % CPR;
@@ -152,8 +153,9 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             // hides under them (the plain read -> wait -> MFMA chain spent most of a chunk in s_waitcnt lgkmcnt)
             auto load_k = [&](int t, bf16x8 (&kf)[4]) {
                 const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
+                const int sw = (r32 >> 1) & 7;                         // (32 t contributes 0 to (row >> 1) & 7)
 #pragma unroll
-                for (int st = 0; st < 4; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kr + (16 * st + 8 * half) * 2);
+                for (int st = 0; st < 4; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kr + (((2 * st + half) ^ sw) << 4));
             };
             bf16x8 kfa[4], kfb[4];
             if (tile(0) >= 0) load_k(tile(0), kfa);
@@ -332,21 +334,36 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         const float inv = 1.0f / sum;
 
         // ---- store: lane = query, registers = d ; 4 consecutive d per register quad
-        if (q < L) {
-            T* orow = out + ((long long)b * L + q) * D + hh * kHD;
+        T* orow = out + ((long long)b * L + (q < L ? q : L - 1)) * D + hh * kHD;
+        if constexpr (sizeof(T) == 2) {
+            // register quads g, g + 1 hold d = 8g + 4 half .. and 8g + 8 + 4 half ..: v_permlane32_swap pairs the two lane halves
+            // into 16 contiguous bytes per lane (d = 8g .. 8g+7 on half 0, 8g+8 .. 8g+15 on half 1), as the GEMM epilogue does
+            // (all lanes take part in the swap; rows past L are dropped at the store)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                uint2 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16_t v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = f2bf(o[dt][4 * g + e] * inv);
+                    v[g] = *reinterpret_cast<const uint2*>(v4);
+                }
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
+                    const uint4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+                    if (q < L) *reinterpret_cast<uint4*>(orow + dt * 32 + 8 * gp + 8 * half) = o4;
+                }
+            }
+        } else if (q < L) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d = dt * 32 + 8 * g + 4 * half;
-                    T v4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = Elem<T>::from_f32(o[dt][4 * g + e] * inv);
-                    if constexpr (sizeof(T) == 2) {
-                        *reinterpret_cast<uint2*>(orow + d) = *reinterpret_cast<const uint2*>(v4);
-                    } else {
-                        *reinterpret_cast<f32x4*>(orow + d) = *reinterpret_cast<const f32x4*>(v4);
-                    }
+                    *reinterpret_cast<f32x4*>(orow + d) = f32x4{o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
                 }
         }
     }
@@ -395,9 +412,10 @@ hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hi
     if (L > kLP || D != H * kHD || L < 1) return hipErrorInvalidValue;
     using Lay = AttnLayout<T>;
     const size_t lds = (size_t)kLP * Lay::kRowK + (size_t)Lay::kVBytes + kPartBytes;
+    const int Lp = make_head_major(L, H).Lp;
     // the <T, 9> specialisation assumes L = 256 + 1 or 2 (one or two real keys / queries in the 9th tile): every shipped config
-    if (L == 257 || L == 258) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
-    else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D);
+    if (L == 257 || L == 258) hipLaunchKernelGGL((attention_kernel<T, 9>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D, Lp);
+    else hipLaunchKernelGGL((attention_kernel<T, 0>), dim3(B * H), dim3(256), lds, s, qkv, out, B, L, H, D, Lp);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include "../../include/duodiff_dev.h"
 #include "dd_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,10 @@ struct dd_ctx {
     int64_t* y_stage = nullptr;
     size_t x_stage_elems = 0, y_stage_elems = 0;
     long long graph_captures = 0;
+    // dd_sample_affine: the step table on the device (+ its host staging copy, which must outlive the async upload)
+    AffineRow* atab = nullptr;
+    size_t atab_rows = 0;
+    std::vector<AffineRow> atab_host;
     unsigned dev_flags = 0;      // dd_dev_set_flags (include/duodiff_dev.h): kernel-variant switches of the development harness
 };
 
@@ -64,8 +69,12 @@ struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
 
 struct GraphKey {
     const void* x; const void* y; int B, noise, variance, num_cus;   // num_cus: the captured persistent grids are sized from it
+    const void* atab;                                                // dd_sample_affine's table (null: the DDPM update)
+    const void *aux0 = nullptr, *aux1 = nullptr;                     // dd_sample_early_exit: the two log tables
+    float thr = 0.f;                                                 //                        and the threshold
     bool operator==(const GraphKey& o) const {
-        return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance && num_cus == o.num_cus;
+        return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance && num_cus == o.num_cus &&
+               atab == o.atab && aux0 == o.aux0 && aux1 == o.aux1 && thr == o.thr;
     }
 };
 
@@ -98,8 +107,10 @@ struct dd_model {
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
-    hipGraphExec_t graph = nullptr;
-    GraphKey gkey{};
+    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
+    GraphKey gkey[3]{};                                      // [2] early-exit step (dd_sample_early_exit)
+    float* ee_ws = nullptr;                                  // dd_sample_early_exit scratch: eps | model_output | cls | outs
+    size_t ee_ws_elems = 0;
     // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
     bool time_fc1 = false;
     std::vector<hipEvent_t> fc1_events;   // pairs, grown on demand
@@ -398,8 +409,11 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             if (m->ee_type == DD_EE_ATTENTION_PROBE) {
                 DD_HIP(c, launch_ee_attn_probe(m->x, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, s));
             } else {
-                const int pi = m->ee_type == DD_EE_MLP_PER_LAYER ? bi : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? ee->t : ee->t * nb + bi;
-                DD_HIP(c, launch_ee_probe(m->x, m->probe_w + (long long)pi * D, m->probe_b + pi, ee->cls + (long long)bi * B, B, L, D, s));
+                // probe row: layer bi | timestep t | (t, layer): t is read from the step state inside the launch (a captured
+                // step replays for every t); dd_forward_early_exit has put int(t) there
+                const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
+                const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
+                DD_HIP(c, launch_ee_probe(m->x, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, B, L, D, c->st, t_mul, add, s));
             }
         }
         if (is_out) {
@@ -412,6 +426,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         h_ready = false;
         {
             GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
+            g.hm = make_head_major(L, m->H);     // head-major: each (q | k | v, head) unit of an image is contiguous (attention.hip)
             DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
         }
         DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
@@ -502,12 +517,54 @@ int check_call(dd_ctx* c, dd_model* m, int B, const int64_t* y_dev) {
 // one sampling step enqueued on s: x <- update(x, model(x, t)) ; t comes from ctx->st
 // advance != 0: the step's last kernel also decrements the device-resident timestep (graph replays / dd_sample)
 int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int noise_mode, const float* z_dev,
-                 int variance, float* eps_out, int B, hipStream_t s, int advance = 0) {
+                 int variance, float* eps_out, int B, hipStream_t s, int advance = 0, const AffineRow* atab = nullptr) {
     int rc = run_model(m, x_dev, nullptr, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, x_dev, z_dev, eps_out, x_dev, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance, advance};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance, advance, atab};
     DD_HIP(c, launch_final(fa, s));
+    return DD_OK;
+}
+
+// dd_sample / dd_sample_affine with graphs: the loop runs on context-owned staging copies of x / y, so the captured step
+// does not depend on the caller's tensor addresses
+int stage_inputs(dd_ctx* c, const float* x_dev, const int64_t* y_dev, int B, size_t x_elems, hipStream_t s, float** x_run,
+                 const int64_t** y_run) {
+    if (c->x_stage_elems < x_elems) {       // grows only: model graphs keyed on the old address are re-captured once
+        if (c->x_stage) (void)hipFree(c->x_stage);
+        c->x_stage = nullptr; c->x_stage_elems = 0;
+        DD_HIP(c, hipMalloc((void**)&c->x_stage, x_elems * sizeof(float)));
+        c->x_stage_elems = x_elems;
+    }
+    if (y_dev && c->y_stage_elems < (size_t)B) {
+        if (c->y_stage) (void)hipFree(c->y_stage);
+        c->y_stage = nullptr; c->y_stage_elems = 0;
+        DD_HIP(c, hipMalloc((void**)&c->y_stage, (size_t)B * sizeof(int64_t)));
+        c->y_stage_elems = (size_t)B;
+    }
+    DD_HIP(c, hipMemcpyAsync(c->x_stage, x_dev, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (y_dev) DD_HIP(c, hipMemcpyAsync(c->y_stage, y_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    *x_run = c->x_stage;
+    *y_run = y_dev ? c->y_stage : nullptr;
+    return DD_OK;
+}
+
+// the model's captured step of kind `which` (0 DDPM, 1 table-driven) for this key: reused, or captured now from enqueue(m)
+template <typename F>
+int get_graph(dd_ctx* c, dd_model* m, int which, const GraphKey& key, hipStream_t s, F&& enqueue) {
+    if (m->graph[which] && m->gkey[which] == key) return DD_OK;
+    if (m->graph[which]) { (void)hipGraphExecDestroy(m->graph[which]); m->graph[which] = nullptr; }
+    hipGraph_t g = nullptr;
+    DD_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int r = enqueue(m);
+    const hipError_t e2 = hipStreamEndCapture(s, &g);
+    if (r) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (e2 != hipSuccess) return fail_hip(c, e2, "hipStreamEndCapture");
+    const hipError_t e3 = hipGraphInstantiate(&m->graph[which], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e3 != hipSuccess) { m->graph[which] = nullptr; return fail_hip(c, e3, "hipGraphInstantiate"); }
+    m->gkey[which] = key;
+    ++c->graph_captures;
     return DD_OK;
 }
 
@@ -591,6 +648,7 @@ void dd_ctx_destroy(dd_ctx* c) {
     if (c->coef) (void)hipFree(c->coef);
     if (c->x_stage) (void)hipFree(c->x_stage);
     if (c->y_stage) (void)hipFree(c->y_stage);
+    if (c->atab) (void)hipFree(c->atab);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -839,7 +897,9 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t Mp = (size_t)m->Mp_max;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(Mp * 3 * D * es);
+    // qkv is head-major: B * 3H units of Lp rows x 64 (rows [L, Lp) stay zero: the workspace is zeroed once, below)
+    const size_t qkv_elems = (size_t)m->cfg.max_batch * 3 * D * (size_t)make_head_major(L, m->H).Lp;
+    const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(std::max(Mp * 3 * D, qkv_elems) * es);
     const size_t o_hid = take(Mp * (size_t)m->hid_ld * es), o_xb = take(Mp * D * es);
     std::vector<size_t> o_sk;
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
@@ -863,8 +923,9 @@ int dd_model_finalize(dd_model* m, int precision) {
 void dd_model_destroy(dd_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    if (m->graph) (void)hipGraphExecDestroy(m->graph);
+    for (auto g : m->graph) if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : m->fc1_events) (void)hipEventDestroy(e);
+    if (m->ee_ws) (void)hipFree(m->ee_ws);
     if (m->warena) (void)hipFree(m->warena);
     if (m->wsarena) (void)hipFree(m->wsarena);
     delete m;
@@ -921,7 +982,7 @@ int dd_early_exit_select(dd_ctx* c, const float* outputs_dev, const float* eps_d
     if (!outputs_dev || !eps_dev || !classifier_dev || !model_output_dev) return fail(c, DD_ERR_INVALID, "null tensor");
     if (depth < 1 || B < 1 || chw < 1) return fail(c, DD_ERR_INVALID, "depth, B and chw must be positive");
     DD_HIP(c, launch_ee_select(outputs_dev, eps_dev, classifier_dev, threshold, depth, B, (long long)chw, model_output_dev,
-                               indices_dev, err_mean_dev, (hipStream_t)stream));
+                               indices_dev, err_mean_dev, nullptr, (hipStream_t)stream));
     return DD_OK;
 }
 
@@ -1000,44 +1061,11 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     const int64_t* y_run = a->y_dev;
     const size_t x_elems = (size_t)a->B * a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
     if (a->use_graph) {
-        if (c->x_stage_elems < x_elems) {       // grows only: model graphs keyed on the old address are re-captured once
-            if (c->x_stage) (void)hipFree(c->x_stage);
-            c->x_stage = nullptr; c->x_stage_elems = 0;
-            DD_HIP(c, hipMalloc((void**)&c->x_stage, x_elems * sizeof(float)));
-            c->x_stage_elems = x_elems;
-        }
-        if (a->y_dev && c->y_stage_elems < (size_t)a->B) {
-            if (c->y_stage) (void)hipFree(c->y_stage);
-            c->y_stage = nullptr; c->y_stage_elems = 0;
-            DD_HIP(c, hipMalloc((void**)&c->y_stage, (size_t)a->B * sizeof(int64_t)));
-            c->y_stage_elems = (size_t)a->B;
-        }
-        DD_HIP(c, hipMemcpyAsync(c->x_stage, a->x_dev, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if (a->y_dev) DD_HIP(c, hipMemcpyAsync(c->y_stage, a->y_dev, (size_t)a->B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-        x_run = c->x_stage;
-        y_run = a->y_dev ? c->y_stage : nullptr;
-    }
-    auto get_graph = [&](dd_model* m) -> int {
-        GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance, c->num_cus};
-        if (m->graph && m->gkey == key) return DD_OK;
-        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
-        hipGraph_t g = nullptr;
-        DD_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
-        hipError_t e2 = hipStreamEndCapture(s, &g);
-        if (r) { if (g) (void)hipGraphDestroy(g); return r; }
-        if (e2 != hipSuccess) return fail_hip(c, e2, "hipStreamEndCapture");
-        hipError_t e3 = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e3 != hipSuccess) { m->graph = nullptr; return fail_hip(c, e3, "hipGraphInstantiate"); }
-        m->gkey = key;
-        ++c->graph_captures;
-        return DD_OK;
-    };
-
-    if (a->use_graph) {
-        if ((rc = get_graph(a->first))) return rc;
-        if (switching && (rc = get_graph(a->late))) return rc;
+        if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, x_elems, s, &x_run, &y_run))) return rc;
+        const GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance, c->num_cus, nullptr};
+        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1); };
+        if ((rc = get_graph(c, a->first, 0, key, s, step))) return rc;
+        if (switching && (rc = get_graph(c, a->late, 0, key, s, step))) return rc;
     }
     DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
     DD_HIP(c, hipEventRecord(c->ev[0], s));
@@ -1045,7 +1073,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     dd_model* cur = a->first;
     for (int t = a->t_start; t >= a->t_end; --t) {
         if (a->use_graph) {
-            DD_HIP(c, hipGraphLaunch(cur->graph, s));
+            DD_HIP(c, hipGraphLaunch(cur->graph[0], s));
         } else {
             rc = enqueue_step(c, cur, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
             if (rc) return rc;
@@ -1059,6 +1087,132 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));
     if (x_run != a->x_dev) DD_HIP(c, hipMemcpyAsync(a->x_dev, x_run, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DD_OK;
+}
+
+int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
+    if (!c || !a) return DD_ERR_INVALID;
+    int rc = check_call(c, a->first, a->B, a->y_dev);
+    if (rc) return rc;
+    if (a->late && (rc = check_call(c, a->late, a->B, a->y_dev))) return rc;
+    if (!a->x_dev || !a->t || !a->a || !a->b || !a->c || !a->noise) return fail(c, DD_ERR_INVALID, "null tensor / table");
+    if (a->n_steps < 1 || a->n_steps > (1 << 20)) return fail(c, DD_ERR_INVALID, "n_steps outside [1, 2^20]");
+    if (a->noise_mode != DD_NOISE_PHILOX && a->noise_mode != DD_NOISE_NONE)
+        return fail(c, DD_ERR_INVALID, "dd_sample_affine generates noise on the device; for host noise drive dd_forward + dd_affine_step");
+    if (a->late) {
+        const dd_config &f = a->first->cfg, &l = a->late->cfg;
+        if (f.img_size != l.img_size || f.in_chans != l.in_chans) return fail(c, DD_ERR_INVALID, "first and late model disagree on image shape");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int n = a->n_steps;
+    const bool switching = a->late && a->switch_after >= 0 && a->switch_after < n;
+    // the table: n rows + one more whose timestep the last step hands on (never used)
+    if (c->atab_rows < (size_t)n + 1) {
+        if (c->atab) (void)hipFree(c->atab);
+        c->atab = nullptr; c->atab_rows = 0;
+        DD_HIP(c, hipMalloc((void**)&c->atab, ((size_t)n + 1) * sizeof(AffineRow)));
+        c->atab_rows = (size_t)n + 1;
+    }
+    DD_HIP(c, hipStreamSynchronize(s));            // a previous call's upload may still read the host staging copy
+    c->atab_host.assign((size_t)n + 1, AffineRow{0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0});
+    for (int k = 0; k < n; ++k) c->atab_host[k] = AffineRow{a->t[k], a->a[k], a->b[k], a->c[k], a->noise[k] ? 1 : 0, 0, 0, 0};
+    DD_HIP(c, hipMemcpyAsync(c->atab, c->atab_host.data(), ((size_t)n + 1) * sizeof(AffineRow), hipMemcpyHostToDevice, s));
+
+    float* x_run = a->x_dev;
+    const int64_t* y_run = a->y_dev;
+    const size_t x_elems = (size_t)a->B * a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    if (a->use_graph) {
+        if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, x_elems, s, &x_run, &y_run))) return rc;
+        const GraphKey key{x_run, y_run, a->B, a->noise_mode, 0, c->num_cus, c->atab};
+        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, 0, nullptr, a->B, s, 1, c->atab); };
+        if ((rc = get_graph(c, a->first, 1, key, s, step))) return rc;
+        if (switching && (rc = get_graph(c, a->late, 1, key, s, step))) return rc;
+    }
+    DD_HIP(c, launch_set_state_table(c->st, c->atab, (unsigned long long)a->seed, s));
+    DD_HIP(c, hipEventRecord(c->ev[0], s));
+    bool marked = false;
+    dd_model* cur = a->first;
+    for (int k = 0; k < n; ++k) {
+        if (switching && k == a->switch_after) {
+            cur = a->late;
+            DD_HIP(c, hipEventRecord(c->ev[1], s));
+            marked = true;
+        }
+        if (a->use_graph) {
+            DD_HIP(c, hipGraphLaunch(cur->graph[1], s));
+        } else {
+            rc = enqueue_step(c, cur, x_run, y_run, a->noise_mode, nullptr, 0, nullptr, a->B, s, 1, c->atab);
+            if (rc) return rc;
+        }
+    }
+    if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
+    DD_HIP(c, hipEventRecord(c->ev[2], s));
+    if (x_run != a->x_dev) DD_HIP(c, hipMemcpyAsync(a->x_dev, x_run, x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DD_OK;
+}
+
+// One early-exit sampling step on the device (reference eesampler.py:56-81): EarlyExitUViT.forward with every head and
+// probe -> per-sample exit selection -> DDPM update with the selected output; rows t of the two log tables are written.
+static int enqueue_ee_step(dd_ctx* c, dd_model* m, float* x, const int64_t* y, float thr, float* err_tab, int32_t* idx_tab,
+                           int noise_mode, int B, hipStream_t s) {
+    const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    const int depth = m->cfg.depth;
+    float* eps = m->ee_ws;
+    float* mo = eps + (size_t)B * chw;
+    float* cls = mo + (size_t)B * chw;
+    float* outs = cls + (size_t)depth * B;
+    const EeTaps ee{cls, outs, 0};
+    int rc = run_model(m, x, nullptr, y, B, s, &ee);
+    if (rc) return rc;
+    FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps, nullptr, c->st, c->coef,
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
+    DD_HIP(c, launch_final(fa, s));
+    DD_HIP(c, launch_ee_select(outs, eps, cls, thr, depth, B, chw, mo, idx_tab, err_tab, c->st, s));
+    DD_HIP(c, launch_ddpm_step_state(x, mo, c->st, c->coef, B, m->cfg.in_chans, m->cfg.img_size, noise_mode, 1, s));
+    return DD_OK;
+}
+
+int dd_sample_early_exit(dd_ctx* c, const dd_ee_sample_args* a, void* stream) {
+    if (!c || !a) return DD_ERR_INVALID;
+    dd_model* m = a->model;
+    int rc = check_call(c, m, a->B, a->y_dev);
+    if (rc) return rc;
+    if (m->ee_type < 0) return fail(c, DD_ERR_STATE, "model was not created with dd_model_enable_early_exit");
+    if (!a->x_dev) return fail(c, DD_ERR_INVALID, "null tensor");
+    if (a->t_start > 999 || a->t_end < 0 || a->t_end > a->t_start) return fail(c, DD_ERR_INVALID, "need 999 >= t_start >= t_end >= 0");
+    if (a->noise_mode != DD_NOISE_PHILOX && a->noise_mode != DD_NOISE_NONE)
+        return fail(c, DD_ERR_INVALID, "dd_sample_early_exit generates noise on the device; for host noise drive dd_forward_early_exit");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t chw = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    const size_t need = (size_t)m->cfg.max_batch * ((2 + m->cfg.depth) * chw + m->cfg.depth);
+    if (m->ee_ws_elems < need) {
+        if (m->ee_ws) (void)hipFree(m->ee_ws);
+        m->ee_ws = nullptr; m->ee_ws_elems = 0;
+        DD_HIP(c, hipMalloc((void**)&m->ee_ws, need * sizeof(float)));
+        m->ee_ws_elems = need;
+    }
+    float* x_run = a->x_dev;
+    const int64_t* y_run = a->y_dev;
+    if (a->use_graph) {
+        if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, (size_t)a->B * chw, s, &x_run, &y_run))) return rc;
+        GraphKey key{x_run, y_run, a->B, a->noise_mode, 0, c->num_cus, nullptr};
+        key.aux0 = a->err_dev; key.aux1 = a->idx_dev; key.thr = a->threshold;
+        auto step = [&](dd_model* mm) { return enqueue_ee_step(c, mm, x_run, y_run, a->threshold, a->err_dev, a->idx_dev, a->noise_mode, a->B, s); };
+        if ((rc = get_graph(c, m, 2, key, s, step))) return rc;
+    }
+    DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
+    DD_HIP(c, hipEventRecord(c->ev[0], s));
+    for (int t = a->t_start; t >= a->t_end; --t) {
+        if (a->use_graph) {
+            DD_HIP(c, hipGraphLaunch(m->graph[2], s));
+        } else {
+            rc = enqueue_ee_step(c, m, x_run, y_run, a->threshold, a->err_dev, a->idx_dev, a->noise_mode, a->B, s);
+            if (rc) return rc;
+        }
+    }
+    DD_HIP(c, hipEventRecord(c->ev[1], s));
+    DD_HIP(c, hipEventRecord(c->ev[2], s));
+    if (x_run != a->x_dev) DD_HIP(c, hipMemcpyAsync(a->x_dev, x_run, (size_t)a->B * chw * sizeof(float), hipMemcpyDeviceToDevice, s));
     return DD_OK;
 }
 

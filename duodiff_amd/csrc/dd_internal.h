@@ -47,6 +47,12 @@ struct StepCoef {
     float c1, c2, sigma_tilde, sigma_beta;
 };
 
+// one step of a table-driven loop (dd_sample_affine): x' = a x + b eps + c z, the model sees t_model
+struct AffineRow {
+    float t_model, a, b, c;
+    int noise, pad0, pad1, pad2;
+};
+
 enum GemmEpilogue {
     EPI_STORE = 0,        // out = T(acc)                                  (qkv)
     EPI_BIAS_GELU = 1,    // out = T(gelu_erf(acc + bias))                 (fc1)
@@ -54,6 +60,23 @@ enum GemmEpilogue {
     EPI_BIAS_SET = 3,     // x  = acc + bias                               (skip_linear)
     EPI_BIAS_STORE = 4    // out = T(acc + bias)                           (VAE attention q/k projections)
 };
+
+// Head-major output map of the qkv Linear (what attention.hip reads): element (row m = b * L + l, column c) of the [M, 3D]
+// result lives at ((b * 3H + (c >> 6)) * Lp + l) * 64 + (c & 63) -- the 64 columns of one (q | k | v, head) unit of one image
+// are Lp contiguous 128-byte (bf16) rows, so a GEMM wave stores whole 4 KB blocks and the attention workgroup stages its K / V
+// with linear LDS-DMA.  Lp = L rounded up to 8 (one LDS-DMA piece = 8 rows); rows l >= L are never written (the workspace
+// is zeroed once).  L == 0: plain [M, ldo] rows.
+struct HeadMajor {
+    int L, Lp, H;
+    unsigned magic;     // 2^32 / L + 1:  b = umulhi(m, magic)  (exact for m * L < 2^32)
+};
+inline HeadMajor make_head_major(int L, int H) {
+    return HeadMajor{L, (L + 7) / 8 * 8, H, (unsigned)((1ull << 32) / (unsigned)L + 1ull)};
+}
+__device__ __forceinline__ long long hm_offset(const HeadMajor& hm, int row, int col) {
+    const int b = (int)__umulhi((unsigned)row, hm.magic), l = row - b * hm.L;
+    return (((long long)b * (3 * hm.H) + (col >> 6)) * hm.Lp + l) * 64 + (col & 63);
+}
 
 // C[M,N] = [A | A2][M,K] . W[N,K]^T ; A holds k < K1, A2 holds the rest (concat-free skip GEMM).
 template <typename T>
@@ -66,6 +89,7 @@ struct GemmArgs {
     T* out;            // [Mp, ldo] or null
     int M, N, K, K1;
     int lda, lda2, ldo;
+    HeadMajor hm;      // hm.L != 0: `out` is written head-major (the qkv Linear); N % 64 == 0
 };
 
 // num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
@@ -139,6 +163,7 @@ template <typename T>
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, T* out,
                             int rows, int D, hipStream_t s);
 
+// qkv: head-major (HeadMajor, make_head_major(L, H)); out: [B * L, D] rows
 template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
 
@@ -154,6 +179,8 @@ struct FinalArgs {
     const StepCoef* coef;  // [1000]
     int B, C, S, P, L, extras, noise_mode, variance;
     int advance;
+    const AffineRow* atab; // or null.  Set: st->t is a STEP INDEX k into this table; the update is a x + b eps + c z with row k,
+                           // and advance hands row k + 1's timestep to the next step (the table holds one row more than steps)
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 
@@ -186,10 +213,16 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
 // AttentionProbe operands of one layer (capi.hip finalize folds them): u [D], Wv^T [D, D], bv [D], W0^T [D, D], b0 [D], w2 [D], b2 [1]
 struct AttnProbeW { const float *u, *wvt, *bv, *w0t, *b0, *w2, *b2; };
 hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s);
-hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s);
+// probe row = (t_mul ? st->t_final * t_mul : 0) + add of the [n_probe, D] / [n_probe] tables
+hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, int B, int L, int D,
+                           const StepState* st, int t_mul, int add, hipStream_t s);
+// st != null: idx / err_mean are [1000, B] / [1000, depth] tables and row st->t_final is written
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
-                            float* mo, int* idx, float* err_mean, hipStream_t s);
+                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s);
+hipError_t launch_ddpm_step_state(float* x, const float* eps, StepState* st, const StepCoef* coef, int B, int C, int S,
+                                  int noise_mode, int advance, hipStream_t s);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
+hipError_t launch_set_state_table(StepState* st, const AffineRow* atab, unsigned long long seed, hipStream_t s);   // step index 0
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);
 // (x + 1) / 2, NCHW -> NHWC: the output convention of reference sampler.py:145-146
 hipError_t launch_to_images(const float* x, float* out, int B, int C, int S, hipStream_t s);

@@ -275,8 +275,10 @@ gemm_kernel(const GemmArgs<T> a) {
                     const f32x4 q = *reinterpret_cast<const f32x4*>(strip + sr * STRIP_STRIDE + sc * 16);
                     const int orow = m0 + wr * (BM / WM) + i * 32 + sr;
                     const int ocol = n0 + wc * CW + sc * (16 / (int)sizeof(T));
-                    if (!GUARD || (orow < a.M && ocol < a.N))
-                        *reinterpret_cast<f32x4*>(a.out + (long long)orow * a.ldo + ocol) = q;
+                    if (!GUARD || (orow < a.M && ocol < a.N)) {
+                        const long long off = a.hm.L ? hm_offset(a.hm, orow, ocol) : (long long)orow * a.ldo + ocol;
+                        *reinterpret_cast<f32x4*>(a.out + off) = q;
+                    }
                 }
             }
         }
@@ -539,6 +541,9 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                 // bytes per lane -- columns 8g..8g+7 on h=0, 8g+8..8g+15 on h=1 -- so the slab leaves as 16-byte stores without
                 // the LDS strip round trip (and its lgkmcnt(0) waits) the first version of this epilogue needed.
                 const long long orow = (long long)tm * 256 + wr * 128 + i * 32 + r32;
+                // head-major (qkv): the wave's 64 columns are one (q | k | v, head) unit -- the 32 rows of this slab are
+                // 32 consecutive 128-byte rows of that unit (4 KB contiguous, unless the slab crosses an image boundary)
+                T* obase = a.hm.L ? a.out + hm_offset(a.hm, (int)orow, col0) : a.out + orow * a.ldo + col0;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -546,7 +551,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(v[j][gp].x, v[j][gp + 1].x, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(v[j][gp].y, v[j][gp + 1].y, false, false);
                         const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        *reinterpret_cast<uint4*>(a.out + orow * a.ldo + col0 + j * 32 + 8 * gp + 8 * h) = o;
+                        *reinterpret_cast<uint4*>(obase + j * 32 + 8 * gp + 8 * h) = o;
                     }
             }
         }
@@ -567,7 +572,10 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                         if (RESID) q = *xp + q;
                         *xp = q;
                     }
-                    if (use_out) *reinterpret_cast<uint2*>(a.out + row * a.ldo + col) = pack4(q);
+                    if (use_out) {
+                        const long long off = a.hm.L ? hm_offset(a.hm, (int)row, col) : row * a.ldo + col;
+                        *reinterpret_cast<uint2*>(a.out + off) = pack4(q);
+                    }
                 }
             }
         }
@@ -727,6 +735,7 @@ template <typename T>
 hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int num_cus) {
     constexpr int KT = 128 / (int)sizeof(T);
     if (a.K % KT || a.K1 % KT || a.K1 > a.K || (a.K1 < a.K && !a.A2)) return hipErrorInvalidValue;
+    if (a.hm.L && (a.N % 64 || a.N != 3 * 64 * a.hm.H || (long long)a.M * a.hm.L >= (1ll << 32))) return hipErrorInvalidValue;
     if constexpr (sizeof(T) == 4) {
         if (a.N <= 64) return launch_cfg<T, 128, 64, 2, 2, 2>(a, epilogue, s);  // decoder_pred: N = P*P*C <= 64
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);

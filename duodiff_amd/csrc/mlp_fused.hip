@@ -191,8 +191,11 @@ __device__ __forceinline__ void ln_stats_shifted(float c, float s, float q, floa
     // be spilled, across the whole chunk loop for the epilogue's use), and both lanes evaluate the same expression
     const auto pm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mh), __builtin_bit_cast(unsigned, mh), false, false);
     const auto p2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m2h), __builtin_bit_cast(unsigned, m2h), false, false);
-    const float m_lo = __builtin_bit_cast(float, pm[0]), m_hi = __builtin_bit_cast(float, pm[1]);
-    const float q_lo = __builtin_bit_cast(float, p2[0]), q_hi = __builtin_bit_cast(float, p2[1]);
+    // (elements copied to scalars first: __builtin_bit_cast applied directly to a vector-element expression pm[1] reads
+    // element 0 with this clang -- the difference below came out as v - v)
+    const unsigned u_lo = pm[0], u_hi = pm[1], w_lo = p2[0], w_hi = p2[1];
+    const float m_lo = __builtin_bit_cast(float, u_lo), m_hi = __builtin_bit_cast(float, u_hi);
+    const float q_lo = __builtin_bit_cast(float, w_lo), q_hi = __builtin_bit_cast(float, w_hi);
     mean = 0.5f * (m_lo + m_hi);
     const float d = m_lo - m_hi;
     const float m2 = (q_lo + q_hi) + d * d * (0.5f * n);

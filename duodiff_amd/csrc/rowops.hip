@@ -377,6 +377,24 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
     }
 
     const int t = a.st->t_final;
+    if (a.atab) {   // table-driven loop (dd_sample_affine): t is the step index
+        const AffineRow row = a.atab[t];
+        if (a.advance && pix == 0) { a.st->t = t + 1; a.st->t_model = a.atab[t + 1].t_model; }
+        const bool nz = row.noise != 0 && a.noise_mode == 2;
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (a.x_out && nz) zn = philox_normal4(a.st->seed, (unsigned long long)pix, t);
+        for (int co = 0; co < C; ++co) {
+            const long long e = (((long long)b * C + co) * S + y) * S + x;
+            const float eps = acc[co];
+            if (a.eps_out) a.eps_out[e] = eps;
+            if (a.x_out) {
+                float v = row.a * a.x_in[e] + row.b * eps;      // affine_step_kernel's order and roundings
+                if (nz) v = v + row.c * zn[co];
+                a.x_out[e] = v;
+            }
+        }
+        return;
+    }
     if (a.advance && pix == 0) { a.st->t = t - 1; a.st->t_model = (float)(t - 1); }   // no block of this kernel reads t / t_model
     const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
@@ -414,7 +432,11 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
     // state -> coefficient row, the x_t pixels, the Philox normals) overlaps the halo gather instead of following it:
     // the kernel is a chain of dependent memory round trips, not bandwidth.
     const int t = a.st->t_final;
-    const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
+    const bool table = a.atab != nullptr;      // dd_sample_affine: t is a step index, the update a x + b eps + c z of row t
+    const AffineRow row = table ? a.atab[t] : AffineRow{0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0};
+    const float t_next = (table && a.advance) ? a.atab[t + 1].t_model : 0.f;
+    const StepCoef cf = a.coef[table ? 0 : (t < 0 ? 0 : (t > 999 ? 999 : t))];
+    const bool draw = table ? (row.noise != 0) : (t > 0);
     float xin[4] = {0.f, 0.f, 0.f, 0.f}, zin[4] = {0.f, 0.f, 0.f, 0.f};
     if (inside && a.x_out) {
 #pragma unroll
@@ -422,7 +444,7 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
             if (co < C) {
                 const long long e = (((long long)b * C + co) * S + y) * S + x;
                 xin[co] = a.x_in[e];
-                if (t > 0 && a.noise_mode == 1) zin[co] = a.z[e];
+                if (draw && a.noise_mode == 1) zin[co] = a.z[e];
             }
         }
     }
@@ -444,13 +466,13 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
         for (int ci = 0; ci < C; ++ci) u[ci][hy][hx] = in ? src[ci] : 0.f;
     }
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-    if (inside && a.x_out && t > 0 && a.noise_mode == 2)
+    if (inside && a.x_out && draw && a.noise_mode == 2)
         zn = philox_normal4(a.st->seed, ((unsigned long long)b * S + y) * S + x, t);   // same pixel id as the untiled kernel
     __syncthreads();
     if (a.advance && blockIdx.x == 0 && tid == 0) {   // no block of this kernel reads t / t_model
-        const int tn = t - 1;
+        const int tn = table ? t + 1 : t - 1;
         a.st->t = tn;
-        a.st->t_model = (float)tn;
+        a.st->t_model = table ? t_next : (float)tn;
     }
     if (!inside) return;
     float acc[4];
@@ -480,10 +502,17 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
             const float eps = acc[co];
             if (a.eps_out) a.eps_out[e] = eps;
             if (a.x_out) {
-                float v = cf.c1 * (xin[co] - cf.c2 * eps);
-                if (t > 0) {
-                    if (a.noise_mode == 1) v = v + sigma * zin[co];
-                    else if (a.noise_mode == 2) v = v + sigma * zn[co];
+                float v;
+                if (table) {
+                    v = row.a * xin[co] + row.b * eps;                  // affine_step_kernel's order and roundings
+                    if (draw && a.noise_mode == 1) v = v + row.c * zin[co];
+                    else if (draw && a.noise_mode == 2) v = v + row.c * zn[co];
+                } else {
+                    v = cf.c1 * (xin[co] - cf.c2 * eps);
+                    if (t > 0) {
+                        if (a.noise_mode == 1) v = v + sigma * zin[co];
+                        else if (a.noise_mode == 2) v = v + sigma * zn[co];
+                    }
                 }
                 a.x_out[e] = v;
             }
@@ -500,6 +529,30 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
     float v = c.c1 * (x[i] - c.c2 * eps[i]);
     if (use_noise) v = v + (variance_beta ? c.sigma_beta : c.sigma_tilde) * z[i];
     out[i] = v;
+}
+
+// The same update driven by the device-resident step state (dd_sample_early_exit): t = st->t_final, coefficients from the
+// context's table, z from the Philox generator of the fused step (same counter: pixel, t); advance: one thread hands t - 1
+// to the next step.  x [B, C, S, S] in place; one thread per pixel.
+__global__ void __launch_bounds__(256) ddpm_step_state_kernel(float* __restrict__ x, const float* __restrict__ eps, StepState* st,
+                                                              const StepCoef* __restrict__ coef, int B, int C, int S,
+                                                              int noise_mode, int advance) {
+#pragma clang fp contract(off)
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long hw = (long long)S * S;
+    const int t = st->t_final;
+    if (advance && pix == 0) { st->t = t - 1; st->t_model = (float)(t - 1); }   // no block of this kernel reads t / t_model
+    if (pix >= (long long)B * hw) return;
+    const StepCoef cf = coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
+    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0 && noise_mode == 2) zn = philox_normal4(st->seed, (unsigned long long)pix, t);
+    const long long b = pix / hw, p = pix - b * hw;
+    for (int c = 0; c < C; ++c) {
+        const long long e = (b * C + c) * hw + p;
+        float v = cf.c1 * (x[e] - cf.c2 * eps[e]);
+        if (t > 0 && noise_mode == 2) v = v + cf.sigma_tilde * zn[c];
+        x[e] = v;
+    }
 }
 
 // out = a*x + b*m + c*z, each product rounded (no FMA contraction): the common form of the reference's
@@ -521,6 +574,12 @@ __global__ void set_state_kernel(StepState* st, int t, unsigned long long seed) 
     st->t_model = (float)t;
     st->seed = seed;
 }
+__global__ void set_state_table_kernel(StepState* st, const AffineRow* atab, unsigned long long seed) {
+    st->t = 0;
+    st->t_final = 0;
+    st->t_model = atab[0].t_model;
+    st->seed = seed;
+}
 __global__ void set_state_float_kernel(StepState* st, float t) {
     st->t = (int)t;
     st->t_final = (int)t;
@@ -540,12 +599,16 @@ __global__ void __launch_bounds__(256) to_images_kernel(const float* __restrict_
 // ---- early-exit baseline (reference models/early_exit.py, eesampler.py) --------------------------------------
 // MLPProbe (early_exit.py:31-37): u[b] = mean over the L tokens of sigmoid(x[b,l,:] . w + bias).  One workgroup per
 // image, one wave per token row (coalesced 256 B segments), fixed-order reductions (deterministic per image).
-__global__ void __launch_bounds__(256) ee_probe_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ out, int L,
-                                                       int D) {
+// probe row pi = t * t_mul + add with t = the step's timestep on the device (StepState::t_final): per-timestep probes are
+// selected inside the launch, so a captured step replays for every t (matrix[key], reference early_exit.py:219-240)
+__global__ void __launch_bounds__(256) ee_probe_kernel(const float* __restrict__ x, const float* __restrict__ w_base,
+                                                       const float* __restrict__ bias_base, float* __restrict__ out, int L,
+                                                       int D, const StepState* __restrict__ st, int t_mul, int add) {
     __shared__ float part[4];
     const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float bv = bias[0];
+    const int pi = (t_mul ? st->t_final * t_mul : 0) + add;
+    const float* w = w_base + (long long)pi * D;
+    const float bv = bias_base[pi];
     float acc = 0.f;
     for (int l = wave; l < L; l += 4) {
         const float* xr = x + ((long long)b * L + l) * D;
@@ -623,9 +686,11 @@ __global__ void __launch_bounds__(256) ee_attn_probe_kernel(const float* __restr
 // eesampler.py:61-67: idx[b] = first layer i in [0, depth] with c[i][b] <= threshold, where c[depth][b] = 0 closes the
 // list (torch.argmax of an all-False column is 0); model_output[b] = (outputs ++ [eps])[idx[b]][b].
 __global__ void ee_select_kernel(const float* __restrict__ outs, const float* __restrict__ eps, const float* __restrict__ cls,
-                                 float thr, int depth, int B, long long chw, float* __restrict__ mo, int* __restrict__ idx_out) {
+                                 float thr, int depth, int B, long long chw, float* __restrict__ mo, int* __restrict__ idx_out,
+                                 const StepState* __restrict__ st) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * chw) return;
+    if (st && idx_out) idx_out += (long long)st->t_final * B;     // row t of indices_by_timestep (eesampler.py:71)
     const int b = (int)(i / chw);
     int idx = -1;
     for (int k = 0; k < depth && idx < 0; ++k)
@@ -636,8 +701,10 @@ __global__ void ee_select_kernel(const float* __restrict__ outs, const float* __
 }
 
 // eesampler.py:70: per-layer mean over the batch of the predicted errors (logging)
-__global__ void __launch_bounds__(64) ee_batch_mean_kernel(const float* __restrict__ cls, float* __restrict__ err, int B) {
+__global__ void __launch_bounds__(64) ee_batch_mean_kernel(const float* __restrict__ cls, float* __restrict__ err, int B,
+                                                           const StepState* __restrict__ st) {
     const int k = blockIdx.x, lane = threadIdx.x;
+    if (st) err += (long long)st->t_final * gridDim.x;            // row t of error_prediction_by_timestep (eesampler.py:70)
     float a = 0.f;
     for (int b = lane; b < B; b += 64) a += cls[(long long)k * B + b];
 #pragma unroll
@@ -846,8 +913,9 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
     return hipGetLastError();
 }
 
-hipError_t launch_ee_probe(const float* x, const float* w, const float* bias, float* out, int B, int L, int D, hipStream_t s) {
-    hipLaunchKernelGGL(ee_probe_kernel, dim3(B), dim3(256), 0, s, x, w, bias, out, L, D);
+hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, int B, int L, int D,
+                           const StepState* st, int t_mul, int add, hipStream_t s) {
+    hipLaunchKernelGGL(ee_probe_kernel, dim3(B), dim3(256), 0, s, x, w_base, bias_base, out, L, D, st, t_mul, add);
     return hipGetLastError();
 }
 hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s) {
@@ -855,15 +923,26 @@ hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out,
     return hipGetLastError();
 }
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
-                            float* mo, int* idx, float* err_mean, hipStream_t s) {
+                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s) {
     const long long n = (long long)B * chw;
-    hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx);
-    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B);
+    hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx, st);
+    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B, st);
+    return hipGetLastError();
+}
+hipError_t launch_ddpm_step_state(float* x, const float* eps, StepState* st, const StepCoef* coef, int B, int C, int S,
+                                  int noise_mode, int advance, hipStream_t s) {
+    const long long npix = (long long)B * S * S;
+    hipLaunchKernelGGL(ddpm_step_state_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, eps, st, coef, B, C, S,
+                       noise_mode, advance);
     return hipGetLastError();
 }
 
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, t, seed);
+    return hipGetLastError();
+}
+hipError_t launch_set_state_table(StepState* st, const AffineRow* atab, unsigned long long seed, hipStream_t s) {
+    hipLaunchKernelGGL(set_state_table_kernel, dim3(1), dim3(1), 0, s, st, atab, seed);
     return hipGetLastError();
 }
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s) {

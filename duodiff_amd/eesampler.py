@@ -6,7 +6,8 @@
 Per step (eesampler.py:56-81): EarlyExitUViT.forward -> per-sample exit selection with the global threshold ->
 DDPM update with sigma_t = sqrt(beta-tilde_t).  As in the reference the exit is *simulated*: every layer runs and
 the per-sample output is gathered afterwards.  z comes from the torch CPU generator (``--noise torch_cpu``, the
-stream a CPU run of the reference draws from) or is drawn on the device (``--noise device``).
+stream a CPU run of the reference draws from) or the whole loop runs on the device (``--noise device``: dd_sample_early_exit, one
+hipGraph replay per step, Philox noise).
 """
 import time
 from argparse import ArgumentParser
@@ -36,17 +37,25 @@ def get_samples(model, batch_size: int, seed: int, num_channels: int, sample_hei
         y = torch.as_tensor(y).to(device, torch.int64).contiguous()
     err_dev = torch.zeros(1000, depth, device=device)
     ind_dev = torch.zeros(1000, batch_size, device=device, dtype=torch.int32)
-    for t in range(999, 999 - int(num_steps), -1):
-        time_tensor = t * torch.ones(batch_size, device=device)
-        eps, cls, outs = model.forward_device(x, time_tensor, y)                       # :58-59
-        mo, idx, err = ctx.early_exit_select(outs, eps, cls, threshold)                  # :61-67
-        err_dev[t] = err                                                                  # :70-71 (D2D row copies)
-        ind_dev[t] = idx
-        if t > 0:                                                                         # :77
-            z = torch.randn(x.shape).to(device) if noise == "torch_cpu" else torch.randn(x.shape, device=device)
-        else:
-            z = None
-        ctx.ddpm_step(x, mo, z, t, variance="beta_tilde", out=x)                          # :73-81
+    if noise in ("device", "device_eager", "device_none"):
+        # the whole loop on the device (dd_sample_early_exit): one hipGraph replay per step, z from the device Philox
+        # generator ("device_none": no noise term, "device_eager": the same launches without the graph -- tests / timing)
+        from .engine import sample_early_exit_loop
+        sample_early_exit_loop(ctx, model.engine_model(batch_size), x, threshold, t_start=999, t_end=1000 - int(num_steps), y=y,
+                               seed=seed, noise="none" if noise == "device_none" else "philox", err=err_dev, idx=ind_dev,
+                               use_graph=noise != "device_eager")
+    else:
+        for t in range(999, 999 - int(num_steps), -1):
+            time_tensor = t * torch.ones(batch_size, device=device)
+            eps, cls, outs = model.forward_device(x, time_tensor, y)                       # :58-59
+            mo, idx, err = ctx.early_exit_select(outs, eps, cls, threshold)                  # :61-67
+            err_dev[t] = err                                                                  # :70-71 (D2D row copies)
+            ind_dev[t] = idx
+            if t > 0 and noise != "none":                                                     # :77
+                z = torch.randn(x.shape).to(device) if noise == "torch_cpu" else torch.randn(x.shape, device=device)
+            else:
+                z = None
+            ctx.ddpm_step(x, mo, z, t, variance="beta_tilde", out=x)                          # :73-81
     if autoencoder is not None:
         x = autoencoder.decode(x)
     samples = ((x + 1) / 2).permute(0, 2, 3, 1).contiguous()

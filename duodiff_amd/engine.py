@@ -272,3 +272,70 @@ def sample_loop(ctx: Context, first: Model, late, x, *, t_switch=0, t_start=999,
     else:
         ctx.check(ctx.lib.dd_sample(ctx.handle, C.byref(args), _stream_ptr(cur)))
     return x
+
+
+def sample_affine_loop(ctx: Context, first: Model, late, x, t, a, b, c, noise_flags, *, switch_after=None, y=None, seed=0,
+                       noise="philox", use_graph=True, stream=None):
+    """dd_sample_affine: the table-driven loops (DDIM, predict_original / predict_previous) on the device, in place on x:
+    x <- a[k] x + b[k] model(x, t[k]) + c[k] z for k = 0 .. len(t) - 1; the late model runs from step switch_after on."""
+    n = len(t)
+    f32 = lambda v: np.ascontiguousarray(v, np.float32)
+    tt, aa, bb, cc = f32(t), f32(a), f32(b), f32(c)
+    nz = np.ascontiguousarray(noise_flags, np.int32)
+    assert tt.shape == aa.shape == bb.shape == cc.shape == nz.shape == (n,)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    args = L.dd_affine_sample_args()
+    args.first = first.handle
+    args.late = late.handle if late is not None else None
+    args.n_steps = n
+    args.switch_after = n if (late is None or switch_after is None) else int(switch_after)
+    args.t, args.a, args.b, args.c = (v.ctypes.data_as(fp) for v in (tt, aa, bb, cc))
+    args.noise = nz.ctypes.data_as(ip)
+    args.noise_mode = {"none": L.DD_NOISE_NONE, "philox": L.DD_NOISE_PHILOX}[noise]
+    args.use_graph = int(bool(use_graph))
+    args.seed = int(seed)
+    args.y_dev = y.data_ptr() if y is not None else None
+    args.x_dev = x.data_ptr()
+    args.B = x.shape[0]
+    cur = stream if stream is not None else torch.cuda.current_stream(x.device)
+    if use_graph and cur.cuda_stream == 0:      # no capture on the legacy default stream (see sample_loop)
+        side = ctx.side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ctx.check(ctx.lib.dd_sample_affine(ctx.handle, C.byref(args), _stream_ptr(side)))
+        cur.wait_stream(side)
+    else:
+        ctx.check(ctx.lib.dd_sample_affine(ctx.handle, C.byref(args), _stream_ptr(cur)))
+    return x
+
+
+def sample_early_exit_loop(ctx: Context, model: Model, x, threshold, *, t_start=999, t_end=0, y=None, seed=0, noise="philox",
+                           err=None, idx=None, use_graph=True, stream=None):
+    """dd_sample_early_exit: the early-exit baseline's loop (eesampler.py:40-89) on the device, in place on x.
+    err [1000, depth] fp32 / idx [1000, B] int32 device tensors (or None): rows t_start .. t_end are written."""
+    args = L.dd_ee_sample_args()
+    args.model = model.handle
+    args.threshold = float(threshold)
+    args.t_start, args.t_end = int(t_start), int(t_end)
+    args.noise_mode = {"none": L.DD_NOISE_NONE, "philox": L.DD_NOISE_PHILOX}[noise]
+    args.use_graph = int(bool(use_graph))
+    args.B = x.shape[0]
+    args.seed = int(seed)
+    args.y_dev = y.data_ptr() if y is not None else None
+    args.x_dev = x.data_ptr()
+    if err is not None:
+        assert err.is_cuda and err.dtype == torch.float32 and err.is_contiguous() and err.shape[0] == 1000
+    if idx is not None:
+        assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and tuple(idx.shape) == (1000, x.shape[0])
+    args.err_dev = err.data_ptr() if err is not None else None
+    args.idx_dev = idx.data_ptr() if idx is not None else None
+    cur = stream if stream is not None else torch.cuda.current_stream(x.device)
+    if use_graph and cur.cuda_stream == 0:      # no capture on the legacy default stream (see sample_loop)
+        side = ctx.side_stream(x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ctx.check(ctx.lib.dd_sample_early_exit(ctx.handle, C.byref(args), _stream_ptr(side)))
+        cur.wait_stream(side)
+    else:
+        ctx.check(ctx.lib.dd_sample_early_exit(ctx.handle, C.byref(args), _stream_ptr(cur)))
+    return x

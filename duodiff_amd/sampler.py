@@ -26,7 +26,7 @@ import torch
 
 from .config import ModelParams, load_config
 from .autoencoder import get_autoencoder
-from .engine import Context, sample_loop, schedule_tables
+from .engine import Context, sample_affine_loop, sample_loop, schedule_tables
 from .uvit import UViT
 
 
@@ -151,37 +151,71 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
     def draw(shape):
         return torch.randn(shape).to(device) if noise == "torch_cpu" else torch.randn(shape, device=device)
 
+    def affine_segments(steps, switch_after):
+        """noise == "device": the table-driven loop on the device (dd_sample_affine: one hipGraph replay per step, Philox z),
+        cut at the save points.  steps: [(t, a, b, c, draws_noise, saves_after)]."""
+        k0 = 0
+        while k0 < len(steps):
+            k1 = next((k + 1 for k in range(k0, len(steps)) if steps[k][5]), len(steps))
+            seg = steps[k0:k1]
+            sw = None if switch_after is None else min(max(switch_after - k0, 0), len(seg))
+            seg_first, seg_late = (first, late) if (sw is None or sw > 0) else (late, None)
+            sample_affine_loop(ctx, seg_first, seg_late if sw is not None and 0 < sw < len(seg) else None, x,
+                               [v[0] for v in seg], [v[1] for v in seg], [v[2] for v in seg], [v[3] for v in seg],
+                               [int(v[4]) for v in seg], switch_after=sw, y=y, seed=seed + k0, noise="philox", use_graph=use_graph)
+            if seg[-1][5]:
+                intermediate.append(x.clone())
+            k0 = k1
+
     if use_ddim:
         # reference sampler.py:103-126.  U-ViT forward on the engine + one fused affine update per step.
-        eps = torch.empty_like(x)
-        cur = first
         ts = np.linspace(0, 999, ddim_steps).astype(int)[::-1]
-        for t, s_ in zip(ts[:-1], ts[1:]):
-            t, s_ = int(t), int(s_)
-            cur.forward(x, float(t), y, out=eps)                             # :108-110
-            a, b, c = affine_coefficients("ddim", t, s_, ddim_eta)           # :112-117
-            z = draw(x.shape) if s_ > 0 else None                            # :119
-            ctx.affine_step(x, eps, z, a, b, c, out=x)                       # :120
-            if late is not None and t < 1000 - t_switch:                     # :122-123
-                cur = late
-            if 1000 - t in saves:                                            # :125-126
-                intermediate.append(x.clone())
+        pairs = [(int(t), int(s_)) for t, s_ in zip(ts[:-1], ts[1:])]
+        if noise == "device":
+            steps, switch_after = [], None
+            for k, (t, s_) in enumerate(pairs):
+                a, b, c = affine_coefficients("ddim", t, s_, ddim_eta)
+                steps.append((float(t), a, b, c, s_ > 0, (1000 - t) in saves))
+                if switch_after is None and late is not None and t < 1000 - t_switch:   # :122-123: from the NEXT step on
+                    switch_after = k + 1
+            affine_segments(steps, switch_after)
+        else:
+            eps = torch.empty_like(x)
+            cur = first
+            for t, s_ in pairs:
+                cur.forward(x, float(t), y, out=eps)                             # :108-110
+                a, b, c = affine_coefficients("ddim", t, s_, ddim_eta)           # :112-117
+                z = draw(x.shape) if s_ > 0 else None                            # :119
+                ctx.affine_step(x, eps, z, a, b, c, out=x)                       # :120
+                if late is not None and t < 1000 - t_switch:                     # :122-123
+                    cur = late
+                if 1000 - t in saves:                                            # :125-126
+                    intermediate.append(x.clone())
     elif postprocessing is not predict_noise_postprocessing:
         # predict_original / predict_previous (sampler.py:59-79): same loop, affine update
         kind = {predict_original_postprocessing: "predict_original",
                 predict_previous_postprocessing: "predict_previous"}.get(postprocessing)
         if kind is None:
             raise ValueError("postprocessing must be one of this module's predict_*_postprocessing functions")
-        eps = torch.empty_like(x)
-        cur = first
-        for t in range(999, t_last - 1, -1):
-            cur.forward(x, float(t), y, out=eps)
-            a, b, c = affine_coefficients(kind, t)
-            ctx.affine_step(x, eps, draw(x.shape) if t > 0 else None, a, b, c, out=x)
-            if switch_t is not None and t == switch_t:
-                cur = late
-            if 1000 - t in saves:
-                intermediate.append(x.clone())
+        if noise == "device":
+            steps, switch_after = [], None
+            for k, t in enumerate(range(999, t_last - 1, -1)):
+                a, b, c = affine_coefficients(kind, t)
+                steps.append((float(t), a, b, c, t > 0, (1000 - t) in saves))
+                if switch_t is not None and t == switch_t:
+                    switch_after = k + 1
+            affine_segments(steps, switch_after)
+        else:
+            eps = torch.empty_like(x)
+            cur = first
+            for t in range(999, t_last - 1, -1):
+                cur.forward(x, float(t), y, out=eps)
+                a, b, c = affine_coefficients(kind, t)
+                ctx.affine_step(x, eps, draw(x.shape) if t > 0 else None, a, b, c, out=x)
+                if switch_t is not None and t == switch_t:
+                    cur = late
+                if 1000 - t in saves:
+                    intermediate.append(x.clone())
     elif noise == "device":
         # segments between save points; each segment is one dd_sample call (graph replays)
         stops = sorted({1000 - s for s in saves if t_last <= 1000 - s <= 999}, reverse=True)

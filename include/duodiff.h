@@ -188,6 +188,52 @@ typedef struct dd_sample_args {
 } dd_sample_args;
 int dd_sample(dd_ctx* ctx, const dd_sample_args* args, void* stream);
 
+/* ---- the other loops of get_samples as device-resident loops: DDIM (sampler.py:103-126) and the predict_original /
+ * predict_previous parametrisations (:59-79, :128-139).  Every one of them is  x' = a_k x + b_k model(x, t_k) + c_k z  per
+ * step with host-computed scalars (duodiff_amd/sampler.py affine_coefficients, from the bit-exact schedule tables); the
+ * table lives on the device, the step's last kernel applies row k and advances the device-resident step index, so one
+ * captured hipGraph per backbone is replayed n_steps times (use_graph) -- or the same launches are issued eagerly, bit for bit
+ * the same results.  z: device Philox (counter = step index) or none. */
+typedef struct dd_affine_sample_args {
+    dd_model* first;        /* model used from step 0                                                           */
+    dd_model* late;         /* or NULL; runs from step index switch_after on                                    */
+    int32_t n_steps;        /* number of updates                                                                */
+    int32_t switch_after;   /* >= n_steps (or late == NULL): never                                              */
+    const float* t;         /* host [n_steps]: the timestep the model sees at step k                            */
+    const float* a;         /* host [n_steps]                                                                   */
+    const float* b;         /* host [n_steps]                                                                   */
+    const float* c;         /* host [n_steps]                                                                   */
+    const int32_t* noise;   /* host [n_steps]: != 0: the c z term is added at step k (the reference skips it at its last step) */
+    int32_t noise_mode;     /* DD_NOISE_PHILOX or DD_NOISE_NONE (c z never added)                               */
+    int32_t use_graph;
+    uint64_t seed;
+    const int64_t* y_dev;   /* [B] or NULL                                                                      */
+    float* x_dev;           /* in / out, [B,C,S,S] fp32                                                         */
+    int32_t B;
+    int32_t reserved;
+} dd_affine_sample_args;
+int dd_sample_affine(dd_ctx* ctx, const dd_affine_sample_args* args, void* stream);
+
+/* The early-exit baseline's loop (reference eesampler.py:40-89) as a device-resident loop: per step EarlyExitUViT.forward
+ * (all heads and probes), the per-sample exit selection with the global threshold, the DDPM update (sigma^2 = beta-tilde)
+ * with the selected output; row t of err_dev [1000, depth] (batch-mean predicted error per layer, :70) and of idx_dev
+ * [1000, B] (exit layer per sample, :71) is written when the pointer is non-NULL.  One hipGraph for the step, replayed. */
+typedef struct dd_ee_sample_args {
+    dd_model* model;        /* created with dd_model_enable_early_exit                        */
+    float threshold;
+    int32_t t_start;        /* normally 999                                                   */
+    int32_t t_end;          /* normally 0 (inclusive)                                         */
+    int32_t noise_mode;     /* DD_NOISE_PHILOX or DD_NOISE_NONE                               */
+    int32_t use_graph;
+    int32_t B;
+    uint64_t seed;
+    const int64_t* y_dev;   /* [B] or NULL                                                    */
+    float* x_dev;           /* in / out                                                       */
+    float* err_dev;         /* [1000, depth] fp32 or NULL                                     */
+    int32_t* idx_dev;       /* [1000, B] int32 or NULL                                        */
+} dd_ee_sample_args;
+int dd_sample_early_exit(dd_ctx* ctx, const dd_ee_sample_args* args, void* stream);
+
 /* ---- KL-VAE decode: autoencoder.decode(x) at sampler.py:141-143 ---------------- */
 /* Replaces FrozenAutoencoderKL.decode (models/utils/autoencoder.py:486-490, Decoder :320-449) for the fixed ddconfig of
  * get_autoencoder (:503-516).  Parameters are set by the reference state_dict keys ("decoder.*", "post_quant_conv.*";
