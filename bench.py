@@ -61,6 +61,7 @@ def parse(argv=None):
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_batch", type=int, default=0)
     p.add_argument("--cpu_steps", type=int, default=0)
+    p.add_argument("--dev_flags", type=int, default=0, help="dd_dev_set_flags value (include/duodiff_dev.h): same-process kernel-variant A/B runs only")
     return p.parse_args(argv)
 
 
@@ -187,6 +188,10 @@ def main():
     mp_f = ModelParams.from_dict(load_config(REPO / "configs" / f"{cfg_f}.yaml"))
     sd_s, sd_f = synthetic_state_dict(mp_s, 1237), synthetic_state_dict(mp_f, 1236)
     dev = f"cuda:{local_rank}"
+    if a.dev_flags:
+        from duodiff_amd.engine import Context
+        c0 = Context.get(dev)
+        c0.check(c0.lib.dd_dev_set_flags(c0.handle, a.dev_flags))
     shallow = UViT(**mp_s.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_s).to(dev)
     full = UViT(**mp_f.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_f).to(dev)
     es, ef = shallow.engine_model(B), full.engine_model(B)
@@ -312,7 +317,7 @@ def main():
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],
                        # wall time of the timed region (MAX over ranks) minus the slowest rank's GPU time of the K steps: output kernel,
                        # the all_gather, barriers, rank skew and host launch overhead together
-                       "non_step_ms": dt * 1000.0 - gpu_ms_max,
+                       "non_step_ms": dt * 1000.0 - gpu_ms_max, "dev_flags": a.dev_flags,
                        "library_build_id": build_id},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,

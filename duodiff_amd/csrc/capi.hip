@@ -105,6 +105,8 @@ struct dd_model {
     std::vector<AttnProbeW> attn_probes;                  // DD_EE_ATTENTION_PROBE: one per layer
     bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
+    bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
+                                          //     whose heads read every block's output)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
@@ -391,6 +393,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
     const int nb = (int)m->blocks.size();
     bool h_ready = false;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one)
+    bool skip_done = false; // ... and x already holds that block's skip_linear output (the previous fused launch ran it too)
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
@@ -416,12 +419,13 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, launch_ee_probe(m->x, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, B, L, D, c->st, t_mul, add, s));
             }
         }
-        if (is_out) {
+        if (is_out && !skip_done) {
             const int oi = bi - m->half_depth - 1;
             const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
         }
+        skip_done = false;
         if (!h_ready) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
         h_ready = false;
         {
@@ -459,12 +463,28 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 }
                 fa.xres = m->x; fa.out = (bf16_t*)copy; fa.ldo = D; fa.partial = m->mlp_partial;
                 if (m->fused_proj) { fa.ao = (const bf16_t*)ao; fa.bproj = w.proj_b; fa.nproj = D / 32; }
+                const bool skip_next = m->fused_skip && bi >= m->half_depth && bi + 1 < nb;   // the next block starts with skip_linear
+                if (skip_next) {
+                    const BlockW& wn = m->blocks[bi + 1];
+                    const int oi = bi - m->half_depth;                                // index of the NEXT block among the out-blocks
+                    fa.skip = (const bf16_t*)m->skips[m->half_depth - 1 - oi];      // LIFO (uvit.py:374-375)
+                    fa.bskip = wn.skip_b; fa.nskip = D / 16;
+                    fa.ln_out_g = wn.ln1_g; fa.ln_out_b = wn.ln1_b; fa.ln_out = (bf16_t*)h;
+                    h_ready = true; skip_done = true;
+                }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
                 if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
                 if (int rc = mark()) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
                 if (int rc = mark()) return rc;              // (the event pair brackets the fused kernel alone)
-                DD_HIP(c, launch_mlp_reduce(fa, D, s));
+                if (skip_next) {
+                    MlpFusedArgs fr = fa;                    // the reduce kernel finishes y of the extra-token rows (fp32 + the bf16
+                    fr.ln_out = nullptr;                     // copy in xb); their skip_linear + norm1 follow in one small launch
+                    DD_HIP(c, launch_mlp_reduce(fr, D, s));
+                    DD_HIP(c, launch_skip_rows_ln(fa, D, s));
+                } else {
+                    DD_HIP(c, launch_mlp_reduce(fa, D, s));
+                }
                 continue;
             }
         }
@@ -752,10 +772,12 @@ int dd_model_finalize(dd_model* m, int precision) {
     // fused block tail (mlp_fused.hip): bf16 mode only (development A/B runs can switch it off: dd_dev_set_flags)
     m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(c->dev_flags & DD_DEV_NO_FUSED_MLP);
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
+    m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b; bool skip; };
     std::vector<BlockOff> boffs;
-    auto pack_block = [&](const std::string& p, bool skip) {
+    // next_skip: prefix of the block whose skip_linear runs in THIS block's fused launch ("" = none)
+    auto pack_block = [&](const std::string& p, bool skip, const std::string& next_skip) {
         BlockOff o{};
         o.skip = skip;
         o.ln1_g = put_f32(P(p + "norm1.weight").data(), D); o.ln1_b = put_f32(P(p + "norm1.bias").data(), D);
@@ -767,18 +789,23 @@ int dd_model_finalize(dd_model* m, int precision) {
         o.fc1_w = put_mat(P(p + "mlp.fc1.weight")); o.fc2_w = put_mat(P(p + "mlp.fc2.weight"));
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
         if (m->fused_mlp) {
-            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj));
+            const bool with_skip = m->fused_skip && !next_skip.empty();
+            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj, with_skip));
             o.mlp_b1p = put_raw((size_t)hid * 4);
             const size_t proj_bytes = m->fused_proj ? (size_t)D * D * 2 : 0;      // D/32 blocks of Wproj lead the stream
             if (m->fused_proj) mlp_fused_pack_proj(D, P(p + "attn.proj.weight").data(), host_f2bf, (unsigned short*)&host[o.mlp_img]);
             mlp_fused_pack(D, hid, P(p + "mlp.fc1.weight").data(), P(p + "mlp.fc1.bias").data(), P(p + "mlp.fc2.weight").data(),
                            true, host_f2bf, (unsigned short*)&host[o.mlp_img + proj_bytes], (float*)&host[o.mlp_b1p]);
+            if (with_skip)    // the next block's skip_linear: 2 D/32 blocks behind the MLP blocks
+                mlp_fused_pack_skip(D, P(next_skip + "skip_linear.weight").data(), host_f2bf,
+                                    (unsigned short*)&host[o.mlp_img + proj_bytes + (size_t)(hid / 32) * 2 * (D / 16) * 1024]);
         }
         boffs.push_back(o);
     };
-    for (int i = 0; i < m->half_depth; ++i) pack_block("in_blocks." + std::to_string(i) + ".", false);
-    pack_block("mid_block.", false);
-    for (int i = 0; i < m->half_depth; ++i) pack_block("out_blocks." + std::to_string(i) + ".", true);
+    for (int i = 0; i < m->half_depth; ++i) pack_block("in_blocks." + std::to_string(i) + ".", false, "");
+    pack_block("mid_block.", false, m->half_depth > 0 ? "out_blocks.0." : "");
+    for (int i = 0; i < m->half_depth; ++i)
+        pack_block("out_blocks." + std::to_string(i) + ".", true, i + 1 < m->half_depth ? "out_blocks." + std::to_string(i + 1) + "." : "");
 
     // patch-embed weight [D, pd] -> transposed [pd, D] (coalesced over D in the embed kernel)
     std::vector<float> wt((size_t)m->pd * D);
@@ -1297,18 +1324,21 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
 int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_host, const float* w1, const float* b1, const float* w2,
                const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in, const float* ln_out,
                unsigned short* ln_out_host, int iters, void* stream, float* ms_out, const float* ao_host, const float* wproj,
-               const float* bproj) {
+               const float* bproj, const float* skip_host, const float* wskip, const float* bskip) {
     const bool proj = ao_host && wproj && bproj;
+    const bool skp = skip_host && wskip && bskip;
     if (proj && (!ln_in || D % 128)) return DD_ERR_INVALID;   // the projection rides in the LayerNorm-in kernel only
+    if (skp && (!proj || !ln_out || !ln_out_host || (hidden / 32) % 2)) return DD_ERR_INVALID;   // the skip phases ride on the proj-fused launch and end in norm1
     if (!c || !x_host || !w1 || !b1 || !w2 || !b2 || !xres_host || M < 1 || iters < 0 || extras < 0 || (extras > 0 && M % (1 + extras))) return DD_ERR_INVALID;
     if (!mlp_fused_supported(D, hidden)) return fail(c, DD_ERR_UNSUPPORTED, "fused MLP: D in {64,128,256,512}, hidden % 64 == 0");
     hipStream_t s = (hipStream_t)stream;
     const size_t Mp = (size_t)round_up(M, 256);
-    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden, proj) / 2, 0);
+    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden, proj, skp) / 2, 0);
     std::vector<float> b1p(hidden), xr(Mp * D, 0.f);
     for (size_t i = 0; i < (size_t)M * D; ++i) { xh[i] = host_f2bf(x_host[i]); xr[i] = xres_host[i]; }
     if (proj) mlp_fused_pack_proj(D, wproj, host_f2bf, img.data());
     mlp_fused_pack(D, hidden, w1, b1, w2, ln_in != nullptr, host_f2bf, img.data() + (proj ? (size_t)D * D : 0), b1p.data());
+    if (skp) mlp_fused_pack_skip(D, wskip, host_f2bf, img.data() + (proj ? (size_t)D * D : 0) + (size_t)(hidden / 32) * 2 * (D / 16) * 512);
     // extras > 0: the M rows are `M / (1 + extras)` images of one patch token each (drives the hidden-split path);
     // extras == 0: one image of M patch tokens (main tiles only)
     MlpFusedArgs a{};
@@ -1317,8 +1347,8 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     if (c->dev_flags & DD_DEV_MLP_EXTRAS_ONLY) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
     void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
-    void *dAo = nullptr, *dBp = nullptr;
-    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dBp}) if (p) (void)hipFree(p); };
+    void *dAo = nullptr, *dBp = nullptr, *dSk = nullptr, *dBs = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dBp, dSk, dBs}) if (p) (void)hipFree(p); };
 #define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
     DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
     DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
@@ -1349,8 +1379,20 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         a.ao = (const bf16_t*)dAo; a.bproj = (const float*)dBp; a.nproj = D / 32;
         DD_TRY(launch_proj_rows(a, D, s));
     }
+    MlpFusedArgs ar = a;       // (what the reduce launch gets: see run_backbone)
+    if (skp) {
+        std::vector<unsigned short> sh(Mp * D, 0);
+        for (size_t i = 0; i < (size_t)M * D; ++i) sh[i] = host_f2bf(skip_host[i]);
+        DD_TRY(hipMalloc(&dSk, sh.size() * 2)); DD_TRY(hipMalloc(&dBs, D * 4));
+        DD_TRY(hipMemcpy(dSk, sh.data(), sh.size() * 2, hipMemcpyHostToDevice));
+        DD_TRY(hipMemcpy(dBs, bskip, D * 4, hipMemcpyHostToDevice));
+        a.skip = (const bf16_t*)dSk; a.bskip = (const float*)dBs; a.nskip = D / 16;
+        a.out = (bf16_t*)dO;   // y of the extra-token rows travels through the bf16 copy
+        ar = a; ar.ln_out = nullptr;
+    }
     DD_TRY(launch_mlp_fused(a, D, s));
-    DD_TRY(launch_mlp_reduce(a, D, s));
+    DD_TRY(launch_mlp_reduce(ar, D, s));
+    DD_TRY(launch_skip_rows_ln(a, D, s));
     DD_TRY(hipStreamSynchronize(s));
     DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));
     if (out_host) DD_TRY(hipMemcpy(out_host, dO, (size_t)M * D * 2, hipMemcpyDeviceToHost));
@@ -1359,7 +1401,7 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         hipEvent_t e0 = nullptr, e1 = nullptr;
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(a, D, s)); }
+        for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(ar, D, s)); DD_TRY(launch_skip_rows_ln(a, D, s)); }
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -106,6 +106,9 @@ struct MlpFusedArgs {
     const bf16_t* ao;      // nproj > 0: attention output rows [Mp, D]; the kernel adds ao . Wproj^T + bproj to x first
     const float* bproj;    //            (main tiles only: the extra-token rows must already hold x1)
     int nproj;             // D / 32 blocks of Wproj in front of the MLP blocks of wimg, or 0
+    const bf16_t* skip;    // nskip > 0: the NEXT block's skip_linear runs behind the MLP (main tiles): x' = [y | skip] . Wskip^T + bskip
+    const float* bskip;    //            replaces y in xres, ln_out = norm1(x'); skip = the long-skip operand's rows [Mp, D]
+    int nskip;             // 2 * D / 32 blocks of Wskip behind the MLP blocks of wimg (mlp_fused_pack_skip), or 0
     const float* ln_out_g; // with ln_out: LayerNorm of the UPDATED rows, written as bf16 [Mp, D] (next block's norm1)
     const float* ln_out_b;
     bf16_t* ln_out;
@@ -123,8 +126,10 @@ struct MlpFusedArgs {
     int tiles_main, tiles_left, groups, cpg;
 };
 bool mlp_fused_supported(int D, int hidden);
-size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj);
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip);
 void mlp_fused_pack_proj(int D, const float* wp, unsigned short (*to_bf16)(float), unsigned short* img);
+void mlp_fused_pack_skip(int D, const float* ws, unsigned short (*to_bf16)(float), unsigned short* img);
+hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s);
 size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
 void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,

@@ -147,6 +147,19 @@ __device__ __forceinline__ void gap_stmt(f32x16& acc, bf16x8& wa, const bf16x8& 
     }
 }
 
+// A gap without a GELU piece, accumulator in AGPRs, with only the operands it uses (the SKIP phases: 2 NT F statements; the
+// generic statement above declares the GELU constants as operands -- an SGPR float among them -- whether it uses them or not)
+template <int LG, bool READ, int LO>
+__device__ __forceinline__ void gap_plain(f32x16& acc, bf16x8& wa, const bf16x8& xb, unsigned la) {
+    if constexpr (LG >= 0) {
+        if constexpr (READ) asm volatile(DD_S_MFMA_W DD_S_READ : [acc] "+a"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [la] "v"(la), [lg] "i"(LG), [lo] "i"(LO));
+        else asm volatile(DD_S_MFMA_W : [acc] "+a"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [lg] "i"(LG));
+    } else {
+        if constexpr (READ) asm volatile(DD_S_MFMA_N DD_S_READ : [acc] "+a"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [la] "v"(la), [lo] "i"(LO));
+        else asm volatile(DD_S_MFMA_N : [acc] "+a"(acc), [wa] "+v"(wa) : [xb] "v"(xb));
+    }
+}
+
 // the same GELU pieces as statements of their own (D < 512: several pieces per gap)
 template <int K>
 __device__ __forceinline__ void gelu_piece(float va, float vb, const GeluConst& k, GeluPair& r, unsigned& out) {
@@ -216,12 +229,20 @@ struct MlpCfg {
 // PROJ (main tiles, LNIN mode): the attention output projection of the block runs in front of the MLP inside the same
 // launch -- x1 = x + ao . Wproj^T + bproj (reference models/uvit.py:206, Attention.proj :166) accumulates on top of x in the
 // output accumulators, norm2 is taken from those registers, the MLP accumulates on top again: x1 never exists in HBM.
-template <int D, bool LNIN, bool PARTIAL, bool PROJ>
+// SKIP (main tiles of a PROJ launch): the NEXT block's skip_linear + norm1 run behind the MLP inside the same launch --
+// x' = [y | skip] . Wskip^T + bskip (reference models/uvit.py:196-200: the block output y only feeds this Linear, it is never
+// stored), norm1(x') as bf16 (:206).  y goes from the accumulators straight into MFMA B fragments (as norm2's output does
+// in front of fc1), the accumulators restart from bskip, and 2 NT more phases stream the skip weight blocks that follow the
+// MLP blocks in the image: NT blocks of the y half (one column tile x all its k-steps each), then the long-skip operand's
+// half in two passes of NT/2 blocks (two column tiles x half the k-steps each) -- the operand's rows are fetched half at
+// a time into registers that are free at that point, each half a pass ahead of its use.
+template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false>
 __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
     static_assert(!PROJ || (LNIN && !PARTIAL && C::NT % 4 == 0), "proj fusion: main tiles of the LayerNorm-in kernel, D % 128 == 0");
+    static_assert(!SKIP || PROJ, "skip fusion rides on the proj-fused main tiles");
     float* b1s = reinterpret_cast<float*>(smem + C::RING);           // [hidden + 32], in accumulator-register order per chunk
-    float* vecs = b1s + (a.nchunks + 1) * 32;                        // 6 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2 | bproj
+    float* vecs = b1s + (a.nchunks + 1) * 32;                        // 7 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2 | bproj | bskip
     // weight stream: [nproj blocks of Wproj][W1(0) W2(0) W1(1) W2(1) ...]; stream position p lives in ring slot p & 3
     // (nproj % 4 == 0), so the MLP part keeps "block b in slot b & 3" with or without the projection in front
     const char* const wproj = a.wimg;
@@ -279,7 +300,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         // ds_read_b128 -- every lane of a half wants the same 16 bytes -- not as 300+ vector-memory instructions per lane).
         // Every global load is issued before the first LDS write: one memory round trip, not one per vector (hipcc keeps
         // separate load -> ds_write loops serial, which cost each workgroup ~8 round trips before its first MFMA).
-        constexpr int TB = kMaxHidden / 4 / 256, VQ = 6 * (D / 4), VI = (VQ + 255) / 256;
+        constexpr int TB = kMaxHidden / 4 / 256, VQ = 7 * (D / 4), VI = (VQ + 255) / 256;
         const int nb1 = a.nchunks * 8;
         f32x4 tb[TB], tv[VI];
         bool tvok[VI];
@@ -291,7 +312,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 #pragma unroll
         for (int k = 0; k < VI; ++k) {
             const int item = tid + 256 * k, v = item / (D / 4), i = item - v * (D / 4);
-            const float* sp = v == 0 ? a.ln_in_g : v == 1 ? a.ln_in_b : v == 2 ? a.ln_out_g : v == 3 ? a.ln_out_b : v == 4 ? a.b2 : a.bproj;
+            const float* sp = v == 0 ? a.ln_in_g : v == 1 ? a.ln_in_b : v == 2 ? a.ln_out_g : v == 3 ? a.ln_out_b : v == 4 ? a.b2 : v == 5 ? a.bproj : a.bskip;
             tvok[k] = item < VQ && sp != nullptr;
             tv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (tvok[k]) tv[k] = reinterpret_cast<const f32x4*>(sp)[i];
@@ -584,6 +605,16 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         iteration(std::integral_constant<int, 0>{}, c, sA, sB, pA, pB);
         iteration(std::integral_constant<int, 1>{}, c + 1, sB, sA, pB, pA);
     }
+    // SKIP: the first half of the long-skip operand's rows (k-steps 0 .. F/2-1, natural k order) is requested here, under the
+    // tail; the registers of the fc1 input fragments are free from here on
+    bf16x8 sk[C::F / 2];
+    const bf16_t* sr = nullptr;        // this lane's long-skip row (kept across the first skip phases for the second half's loads:
+    if constexpr (SKIP) {              // no address arithmetic -- compiler VALU code -- between the hand-placed MFMAs)
+        bool ok_s;
+        sr = a.skip + row_of(ok_s) * D + 8 * half_of();
+#pragma unroll
+        for (int ks = 0; ks < C::F / 2; ++ks) sk[ks] = *reinterpret_cast<const bf16x8*>(sr + 16 * ks);
+    }
     // tail: GEMM2 of the last chunk; its block W2(c1-1) (slot 3) was confirmed at the last M barrier and the first PD
     // fragments are already in flight
     [&]<int... FI>(std::integer_sequence<int, FI...>) {
@@ -603,7 +634,101 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) asm volatile("" : "+a"(Y[t]));
 
+    if constexpr (SKIP) {
+        // ---- (a) y = Y + b2 as the B fragments of the y half (accumulator k order: the image's y blocks are packed to match),
+        //      (b) the accumulators restart from bskip
+        __builtin_amdgcn_s_barrier();     // every wave's pieces of the first three skip blocks have landed (wait_vmcnt<0> above)
+        {
+            const int hs = half_of();
+            const float* lb2s = vecs + 4 * D + 4 * hs;
+            const float* lbsk = vecs + 6 * D + 4 * hs;
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                acc_pin(Y[t]);
+                const f32x16 yt = Y[t];
+#pragma unroll
+                for (int kq = 0; kq < 2; ++kq) {
+                    const int ks = 2 * t + kq;
+                    unsigned u[4];
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        const int col = 16 * ks + 8 * gq, g = 2 * kq + gq;
+                        f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
+                        q += *reinterpret_cast<const f32x4*>(lb2s + col);
+                        u[2 * gq] = pack2(q[0], q[1]);
+                        u[2 * gq + 1] = pack2(q[2], q[3]);
+                    }
+                    xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(lbsk + 32 * t + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Y[t][4 * g + e] = bq[e];
+                }
+                acc_pin(Y[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- 2 NT phases of F MFMAs; stream position 2 nchunks + p = skip block p, in ring slot p & 3 (nchunks is even): blocks
+        // 0, 1, 2 were requested by the chunk loop's run-ahead and have landed.  Phase p: B operand and column tile
+        //     p <  NT          : y fragments xf[f],            tile p
+        //     p <  NT + NT/2   : sk[f % (F/2)] (first half),   tile 2 (p - NT) + (f >= F/2)
+        //     else             : xf[f % (F/2)] (second half, requested in the middle of phase NT), tile 2 (p - NT - NT/2) + (f >= F/2)
+        // In the middle of phase p: block p+1 landed | barrier | request block p+3 (as the projection phases do).  The 16-byte
+        // loads of the second half sit right behind the requests of phase NT: the two waits that follow count them in.
+        const char* const wskip = wmlp + (size_t)(2 * a.nchunks) * C::BLK;
+        const unsigned lds_lo_s = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
+        const unsigned lds_hi_s = lds_lo_s + 65536u;
+        constexpr int PDs = C::F / 2 < 8 ? C::F / 2 : 8;
+        constexpr int NPs = 2 * C::NT, NGs = NPs * C::F, H2 = C::F / 2;
+        bf16x8 ws[PDs];
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (lds_frag<J * 1024>(ws[J], lds_lo_s), ...);
+        }(std::make_integer_sequence<int, PDs>{});
+        [&]<int... GI>(std::integer_sequence<int, GI...>) {
+            ([&] {
+                constexpr int g = GI, p = g / C::F, f = g % C::F;
+                if constexpr (f == C::F / 2) {
+                    // younger than block p+1's requests at this point: block p+2's, plus (p = NT+1, NT+2) the H2 operand loads
+                    constexpr int extra = (p == C::NT + 1 || p == C::NT + 2) ? H2 : 0;
+                    wait_vmcnt<C::FPW + extra>();
+                    __builtin_amdgcn_s_barrier();
+                    const char* src = uniform_ptr(wskip + (size_t)(p + 3) * C::BLK);
+                    char* dst = smem + ((p + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
+                    [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
+                    if constexpr (p == C::NT) {       // second half of the long-skip rows -> the registers the y fragments have left
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ks = 0; ks < H2; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(sr + 16 * (H2 + ks));
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                constexpr int gn = g + PDs, left = NGs - 1 - g;
+                constexpr int lg_self = left < PDs - 1 ? left : PDs - 1, lg_next = left - 1 < PDs - 1 ? left - 1 : PDs - 1;
+                constexpr int LG = (g & 1) ? -1 : (left >= 1 ? lg_next - (left >= PDs ? 1 : 0) : lg_self);
+                constexpr bool RD = gn < NGs;
+                constexpr int LO = RD ? ((gn / C::F) & 3) * C::BLK + (gn % C::F) * 1024 : 0;
+                constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+                constexpr int tile = p < C::NT ? p : 2 * ((p - C::NT) % (C::NT / 2)) + (f >= H2 ? 1 : 0);
+                if constexpr (p < C::NT)
+                    gap_plain<LG, RD, LOA>(Y[tile], ws[g % PDs], xf[f], LO < 65536 ? lds_lo_s : lds_hi_s);
+                else if constexpr (p < C::NT + C::NT / 2)
+                    gap_plain<LG, RD, LOA>(Y[tile], ws[g % PDs], sk[f % H2], LO < 65536 ? lds_lo_s : lds_hi_s);
+                else
+                    gap_plain<LG, RD, LOA>(Y[tile], ws[g % PDs], xf[f % H2], LO < 65536 ? lds_lo_s : lds_hi_s);
+            }(), ...);
+        }(std::make_integer_sequence<int, NGs>{});
+        wait_vmcnt<0>();     // the run-ahead requests of the padded blocks
+        mfma_drain();
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) asm volatile("" : "+a"(Y[t]));
+    }
+
     // ---- epilogue.  Accumulator layout: lane = token row, register quad g of tile t = columns 32t + 8g + 4h .. +3.
+    // (SKIP: the accumulators hold x' = skip_linear([y | skip]) complete with its bias; no bf16 copy of it is needed)
     const int he = half_of();
     if constexpr (PARTIAL) {
         float* pp = a.partial + ((long long)slab * 128 + wave * 32 + r32) * D + 4 * he;
@@ -642,7 +767,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
-                q += *reinterpret_cast<const f32x4*>(lb2 + 32 * t + 8 * g);
+                if constexpr (!SKIP) q += *reinterpret_cast<const f32x4*>(lb2 + 32 * t + 8 * g);
                 if constexpr (!LNIN) q = xl[t & 1][g] + q;
                 *reinterpret_cast<f32x4*>(xrow + 32 * t + 8 * g) = q;
                 v[g] = uint2{pack2(q[0], q[1]), pack2(q[2], q[3])};
@@ -651,7 +776,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 s4 += dq;
                 q4 += dq * dq;
             }
-            if (a.out) {
+            if (!SKIP && a.out) {
                 // bf16 copy as 16-byte row segments: v_permlane32_swap joins the two lane halves (see gemm.hip)
 #pragma unroll
                 for (int gp = 0; gp < 4; gp += 2) {
@@ -680,7 +805,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 for (int g = 0; g < 4; ++g) {
                     // the updated row is rebuilt from the (read-only) accumulators: cheaper than writing it back in pass 1
                     f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
-                    q += *reinterpret_cast<const f32x4*>(lb2r + 32 * t + 8 * g);
+                    if constexpr (!SKIP) q += *reinterpret_cast<const f32x4*>(lb2r + 32 * t + 8 * g);
                     const f32x4 gv = *reinterpret_cast<const f32x4*>(lg_out + 32 * t + 8 * g), bv = *reinterpret_cast<const f32x4*>(lb_out + 32 * t + 8 * g);
                     const f32x4 w = (q * rstd + shift) * gv + bv;
                     v[g] = uint2{pack2(w[0], w[1]), pack2(w[2], w[3])};
@@ -707,11 +832,11 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 // Either way an optional second LayerNorm (the NEXT block's norm1, models/uvit.py:206) of the updated rows is written
 // as bf16 from the epilogue (a.ln_out), so neither LayerNorm of a block needs a launch or an HBM round trip of x.
 // Workgroups [0, tiles_main) take a main tile each; the rest are the hidden-split workgroups of the extra-token tiles.
-template <int D, bool LNIN, bool PROJ>
+template <int D, bool LNIN, bool PROJ, bool SKIP = false>
 __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.tiles_main) {
-        mlp_body<D, LNIN, false, PROJ>(a, smem, blockIdx.x, 0, a.nchunks, 0);
+        mlp_body<D, LNIN, false, PROJ, SKIP>(a, smem, blockIdx.x, 0, a.nchunks, 0);
     } else {
         const int e = blockIdx.x - a.tiles_main;
         const int lt = e / a.groups, g = e - lt * a.groups;
@@ -845,14 +970,126 @@ __global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
     for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(xr + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
 }
 
+// The extra-token rows of a SKIP launch (they left the fused launch through the hidden-split workgroups and the reduce
+// kernel, which stored y as bf16 in a.out): x' = [y | skip] . Wskip^T + bskip, stored fp32, and norm1(x') as bf16 --
+// what the main tiles do in their SKIP phases.  The kernel is pure latency (B * extras rows against 2 D^2 weights), so it is
+// cut for depth, not throughput: one workgroup per 32 rows with ONE WAVE PER COLUMN TILE (D/32 waves: 64 MFMAs each at
+// D = 512, as two chains), the rows' y and skip operands parked once in LDS (padded rows: conflict-free fragment reads; the
+// y half is read in accumulator k order as two 8-byte pieces per k-step), the weights straight from the image's fragment
+// order, 16 fragments in flight per wave, LayerNorm statistics (two-pass) exchanged through LDS.
+template <int D>
+__global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs a) {
+    using C = MlpCfg<D>;
+    constexpr int H2 = C::F / 2, PITCH = D * 2 + 16, NW = C::NT;
+    extern __shared__ __attribute__((aligned(16))) char srl[];
+    char* ybuf = srl;                       // [32][PITCH]
+    char* sbuf = srl + 32 * PITCH;          // [32][PITCH]
+    float* red = reinterpret_cast<float*>(srl + 64 * PITCH);   // [2][NW][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
+    auto row_of = [&](int i) -> long long {
+        const int q = i < a.n_extra ? i : a.n_extra - 1, b = q / a.tok_e;
+        return (long long)b * a.tok_l + (q - b * a.tok_e);
+    };
+    // ---- park the operand rows: 32 rows x D bf16 each, 16-byte chunks
+    constexpr int CPR = D / 8, ITEMS = 2 * 32 * CPR, PER = (ITEMS + D * 2 - 1) / (D * 2);
+    f32x4 stg[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int it = tid + k * (D * 2), which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
+        const long long row = row_of(blockIdx.x * 32 + r);
+        const bf16_t* src = which == 0 ? a.out + row * a.ldo : a.skip + row * D;
+        stg[k] = it < ITEMS ? *reinterpret_cast<const f32x4*>(src + ch * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // this wave's column tile: weights of the y half (block t), first fragments requested before the operands are parked
+    const int t = wave;
+    const char* const wskip = a.wimg + ((size_t)a.nproj + 2 * (size_t)a.nchunks) * C::BLK;
+    const bf16x8* wy = reinterpret_cast<const bf16x8*>(wskip + (size_t)t * C::BLK) + lane;
+    const bf16x8* ws0 = reinterpret_cast<const bf16x8*>(wskip + (size_t)(C::NT + t / 2) * C::BLK) + (t & 1) * H2 * 64 + lane;
+    const bf16x8* ws1 = reinterpret_cast<const bf16x8*>(wskip + (size_t)(C::NT + C::NT / 2 + t / 2) * C::BLK) + (t & 1) * H2 * 64 + lane;
+    // weight fragment kk of this tile's 2 F k-steps: the y half (block t), then the two passes of the skip half
+    auto wfrag = [&](int kk) -> bf16x8 {
+        return kk < C::F ? wy[kk * 64] : kk < C::F + H2 ? ws0[(kk - C::F) * 64] : ws1[(kk - C::F - H2) * 64];
+    };
+    constexpr int G = 16;                         // fragments in flight: a rolling window, refilled as it is consumed
+    bf16x8 wf[G];
+#pragma unroll
+    for (int f = 0; f < G; ++f) wf[f] = wfrag(f);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int it = tid + k * (D * 2), which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
+        if (it < ITEMS) *reinterpret_cast<f32x4*>((which == 0 ? ybuf : sbuf) + r * PITCH + ch * 16) = stg[k];
+    }
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bskip + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0[4 * g + e] = bq[e]; acc1[4 * g + e] = 0.f; }
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const char* yrow = ybuf + r32 * PITCH + 8 * h;       // accumulator k order: columns 16 ks + 4 h .. +3 and 16 ks + 8 + 4 h .. +3
+    const char* srow = sbuf + r32 * PITCH + 16 * h;      // natural k order: columns 16 ks + 8 h .. +7
+#pragma unroll
+    for (int kk = 0; kk < 2 * C::F; ++kk) {
+        bf16x8 bfr;
+        if (kk < C::F) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(yrow + 32 * kk), hi = *reinterpret_cast<const u32x2*>(yrow + 32 * kk + 16);
+            bfr = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        } else {
+            bfr = *reinterpret_cast<const bf16x8*>(srow + 32 * (kk - C::F));
+        }
+        if (kk & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk % G], bfr, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk % G], bfr, acc0, 0, 0, 0);
+        if (kk + G < 2 * C::F) wf[kk % G] = wfrag(kk + G);
+    }
+    const f32x16 acc = acc0 + acc1;
+    // two-pass LayerNorm statistics over the row's D columns: lane halves via shuffle, the waves via LDS
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s1 += acc[e];
+    s1 += __shfl_xor(s1, 32);
+    if (h == 0) red[wave * 32 + r32] = s1;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w * 32 + r32];
+    const float mean = tot / (float)D;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float d = acc[e] - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) red[(NW + wave) * 32 + r32] = s2;
+    __syncthreads();
+    float tq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tq += red[(NW + w) * 32 + r32];
+    const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-5f);
+    const int idx = blockIdx.x * 32 + r32;
+    if (idx >= a.n_extra) return;
+    const long long row = row_of(idx);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = 32 * t + 8 * g + 4 * h;
+        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(a.xres + row * D + col) = v;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(a.ln_out_g + col), bv = *reinterpret_cast<const f32x4*>(a.ln_out_b + col);
+        const f32x4 w = (v - mean) * rstd * gv + bv;
+        *reinterpret_cast<uint2*>(a.ln_out + row * D + col) = uint2{pack2(w[0], w[1]), pack2(w[2], w[3])};
+    }
+}
+
 template <int D>
 hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
-    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 6 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 6 column vectors
+    const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 7 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 7 column vectors
     const int grid = a.tiles_main + a.tiles_left * a.groups;
+    if (a.nskip > 0 && (a.nproj <= 0 || a.nskip != D / 16 || !a.skip || !a.bskip || !a.ln_out || a.nchunks % 2)) return hipErrorInvalidValue;
     if (a.nproj > 0) {
         if constexpr (D % 128 == 0) {
             if (!a.ln_in_g || !a.ao || !a.bproj || a.nproj != D / 32) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((mlp_fused_kernel<D, true, true>), dim3(grid), dim3(256), lds, s, a);
+            if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((mlp_fused_kernel<D, true, true>), dim3(grid), dim3(256), lds, s, a);
         } else {
             return hipErrorInvalidValue;
         }
@@ -874,13 +1111,43 @@ hipError_t launch_reduce_d(const MlpFusedArgs& a, hipStream_t s) {
 
 }  // namespace
 
+static size_t skip_rows_lds(int D) { return (size_t)64 * (D * 2 + 16) + (size_t)2 * (D / 32) * 32 * sizeof(float); }
+
 bool mlp_fused_supported(int D, int hidden) {
     return (D == 64 || D == 128 || D == 256 || D == 512) && hidden % 64 == 0 && hidden >= 64 && hidden <= kMaxHidden;
 }
 
 // + four blocks: the kernel's DMA runs up to three blocks past the last chunk (branch-free pipeline); never used as data
-size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj) {
-    return ((size_t)(hidden / 32 + 2) * 2 + (with_proj ? D / 32 : 0)) * (D / 16) * 1024;
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip) {
+    return ((size_t)(hidden / 32 + 2) * 2 + (with_proj ? D / 32 : 0) + (with_skip ? D / 16 : 0)) * (D / 16) * 1024;
+}
+
+// skip_linear weight [D, 2D] (nn.Linear layout; input = cat([x, skip]), reference models/uvit.py:199) -> the 2 NT blocks the
+// SKIP phases stream (they follow the MLP blocks in the image):
+//   block p < NT:           output columns 32p .. 32p+31, fragment f = k-step f of the x half, k index in accumulator order
+//                           (its B operand is the block output converted from the accumulators)
+//   block NT + j, j < NT/2: fragments 0 .. F/2-1 = column tile 2j, F/2 .. F-1 = tile 2j+1; k-steps 0 .. F/2-1 of the skip half,
+//                           natural k order (its B operand is the long-skip tensor's rows as loaded)
+//   block NT + NT/2 + j:    the same tiles, k-steps F/2 .. F-1 of the skip half
+void mlp_fused_pack_skip(int D, const float* ws, unsigned short (*to_bf16)(float), unsigned short* img) {
+    const int F = D / 16, NT = D / 32, H2 = F / 2;
+    for (int p = 0; p < 2 * NT; ++p)
+        for (int f = 0; f < F; ++f)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, h = lane >> 5;
+                for (int j = 0; j < 8; ++j) {
+                    int row, k;
+                    if (p < NT) {
+                        row = 32 * p + r;
+                        k = 16 * f + 8 * (j >> 2) + 4 * h + (j & 3);
+                    } else {
+                        const int q = p - NT, pass = q / (NT / 2), jj = q % (NT / 2);
+                        row = 32 * (2 * jj + (f >= H2 ? 1 : 0)) + r;
+                        k = D + 16 * (pass * H2 + f % H2) + 8 * h + j;
+                    }
+                    img[((size_t)p * F + f) * 512 + lane * 8 + j] = to_bf16(ws[(size_t)row * 2 * D + k]);
+                }
+            }
 }
 
 // Wproj [D, D] (nn.Linear layout) -> D/32 blocks in front of the MLP image: block t = output columns 32t .. 32t+31 as the
@@ -946,7 +1213,7 @@ void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const f
 
 hipError_t init_mlp_fused_kernels() {
     hipError_t e = hipSuccess;
-    const int bias = (kMaxHidden + 32 + 6 * 512) * (int)sizeof(float);
+    const int bias = (kMaxHidden + 32 + 7 * 512) * (int)sizeof(float);
 #define DD_ATTR(DV)                                                                                          \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -954,15 +1221,21 @@ hipError_t init_mlp_fused_kernels() {
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 MlpCfg<DV>::RING + bias);                                                    \
-    if constexpr (DV % 128 == 0)                                                                             \
+    if constexpr (DV % 128 == 0) {                                                                           \
         if (e == hipSuccess)                                                                                 \
             e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    MlpCfg<DV>::RING + bias);
+                                    MlpCfg<DV>::RING + bias);                                                \
+        if (e == hipSuccess)                                                                                 \
+            e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    MlpCfg<DV>::RING + bias);                                                \
+    }
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR
 #define DD_ATTR_P(DV)                                                                                        \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void*)proj_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds);
+        e = hipFuncSetAttribute((const void*)proj_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds); \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(DV));
     DD_ATTR_P(128) DD_ATTR_P(256) DD_ATTR_P(512)
 #undef DD_ATTR_P
     return e;
@@ -977,6 +1250,21 @@ hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
         case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(256), kProjRowsLds, s, a); break;
         case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(256), kProjRowsLds, s, a); break;
         case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(256), kProjRowsLds, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// skip_linear + norm1 of the extra-token rows of a SKIP launch (after launch_mlp_reduce, which stored their y in a.out); no-op without extras
+hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s) {
+    if (a.n_extra <= 0 || a.nskip <= 0) return hipSuccess;
+    if (!a.out || !a.skip || !a.bskip || !a.ln_out || !a.ln_out_g || !a.ln_out_b) return hipErrorInvalidValue;
+    const dim3 grid((a.n_extra + 31) / 32);
+    const size_t lds = skip_rows_lds(D);
+    switch (D) {
+        case 128: hipLaunchKernelGGL((skip_rows_ln_kernel<128>), grid, dim3(256), lds, s, a); break;
+        case 256: hipLaunchKernelGGL((skip_rows_ln_kernel<256>), grid, dim3(512), lds, s, a); break;
+        case 512: hipLaunchKernelGGL((skip_rows_ln_kernel<512>), grid, dim3(1024), lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

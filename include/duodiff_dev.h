@@ -19,11 +19,15 @@ extern "C" {
  * ln_out [2, D] + ln_out_host [M, D] bf16 or NULL: LayerNorm of the updated rows from the epilogue.
  * ao_host [M, D] + wproj [D, D] + bproj [D] or NULL (needs ln_in, D % 128 == 0): the attention projection
  * x += ao . wproj^T + bproj runs in front of the MLP in the same launch (extra-token rows: the small kernel the model
- * launches for them). */
+ * launches for them).
+ * skip_host [M, D] + wskip [D, 2D] + bskip [D] or NULL (needs the projection and ln_out): the NEXT block's skip_linear runs
+ * behind the MLP in the same launch -- xres_host then receives x' = cat([y, skip]) . wskip^T + bskip instead of y, and
+ * ln_out_host its LayerNorm (models/uvit.py:196-200, 206). */
 int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
                const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
                const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out,
-               const float* ao_host, const float* wproj, const float* bproj);
+               const float* ao_host, const float* wproj, const float* bproj, const float* skip_host, const float* wskip,
+               const float* bskip);
 
 /* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
  * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
@@ -31,6 +35,7 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
 #define DD_DEV_NO_FUSED_MLP 1u      /* keep the fc1 / fc2 GEMM pair + LayerNorm launches instead of the fused block tail */
 #define DD_DEV_NO_FUSED_PROJ 2u     /* keep attn.proj as its own GEMM */
 #define DD_DEV_NO_FUSED_HEAD 4u     /* keep final LayerNorm + decoder_pred as two launches */
+#define DD_DEV_NO_FUSED_SKIP 32u    /* keep skip_linear as its own GEMM + LayerNorm launch */
 #define DD_DEV_GENERIC_EMBED 8u     /* generic VALU patch-embed kernel */
 #define DD_DEV_MLP_EXTRAS_ONLY 16u  /* dd_dev_mlp: launch the hidden-split (extra-token) workgroups alone */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);

@@ -66,7 +66,7 @@ def test_fused_mlp_against_float64_reference(M, D, extras, ln, proj):
     ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
                                  P(ln_in) if ln else None, P(ln_out) if ln else None, P(hout) if ln else None, 0,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
-                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None))
+                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None, None, None, None))
     scale = float(np.abs(want - x).std())             # size of the block's contribution
     err = np.abs(got - want)
     print(f"M={M} D={D} extras={extras} ln={ln} proj={proj}: max {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (mlp std {scale:.3f})")
@@ -111,7 +111,7 @@ def test_fused_layernorms_on_rows_with_a_large_common_offset(offset, sigma, proj
     ms = C.c_float(0)
     ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
                                  P(ln_in), P(ln_out), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
-                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None))
+                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None, None, None, None))
     contrib = want - x1.astype(np.float64)             # the MLP's contribution, O(1), on top of rows of size |offset|
     scale = float(contrib.std())
     ulp = float(np.spacing(np.float32(4 * abs(offset))))   # fp32 resolution of the stored rows
@@ -128,6 +128,52 @@ def test_fused_layernorms_on_rows_with_a_large_common_offset(offset, sigma, proj
     assert err.max() <= 1.5e-2 * max(scale, 0.1) + 16 * ulp and rms <= 2e-3 * max(scale, 0.1) + 4 * ulp
     # next norm1: bf16 rounding of values of size <= ~4 (2^-8 * 4 = 1.6e-2 max, ~1e-3 rms); a variance off by 1 % would show as 1e-2 rms
     assert herr.max() <= 2.5e-2 and hrms <= 2.5e-3
+
+
+@pytest.mark.parametrize("M,D,extras", [(300, 512, 0), (770, 512, 1), (700, 128, 1), (1500, 256, 0), (258 * 2, 512, 2)])
+def test_fused_tail_with_next_skip_linear(M, D, extras):
+    """The fused launch with the NEXT block's skip_linear + norm1 behind the MLP (reference models/uvit.py:196-200, 206):
+    x' = cat([y, skip]) . Wskip^T + bskip with y = x1 + mlp(norm2(x1)), x1 = x + proj(ao) -- against a float64 reference in
+    which y and skip are rounded to bf16 exactly where the engine rounds them (the Linear's operands).  Patch rows run the skip
+    phases inside the launch, extra-token rows the small kernel behind the reduce; both paths are covered."""
+    from duodiff_amd.engine import Context
+    ctx = Context.get()
+    hidden = 4 * D
+    g = np.random.default_rng(M + D + 17)
+    w1 = (g.standard_normal((hidden, D), dtype=np.float32) * 0.05).astype(np.float32)
+    b1 = (g.standard_normal(hidden, dtype=np.float32) * 0.2).astype(np.float32)
+    w2 = (g.standard_normal((D, hidden), dtype=np.float32) * 0.05).astype(np.float32)
+    b2 = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x = (g.standard_normal((M, D), dtype=np.float32) * 1.5 + 0.3).astype(np.float32)
+    ln_in = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ln_out = np.stack([1 + 0.1 * g.standard_normal(D), 0.05 * g.standard_normal(D)]).astype(np.float32)
+    ao = g.standard_normal((M, D), dtype=np.float32)
+    wp = (g.standard_normal((D, D), dtype=np.float32) * 0.05).astype(np.float32)
+    bp = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    skip = (g.standard_normal((M, D), dtype=np.float32) * 1.2).astype(np.float32)
+    ws = (g.standard_normal((D, 2 * D), dtype=np.float32) * 0.04).astype(np.float32)
+    bs = (g.standard_normal(D, dtype=np.float32) * 0.2).astype(np.float32)
+    x1 = (x.astype(np.float64) + _bf16(ao).astype(np.float64) @ _bf16(wp).astype(np.float64).T + bp.astype(np.float64)).astype(np.float32)
+    y = _reference(_layernorm(x1, ln_in), w1, b1, w2, b2, x1)                      # float64
+    cat = np.concatenate([_bf16(y.astype(np.float32)), _bf16(skip)], axis=1).astype(np.float64)
+    want = cat @ _bf16(ws).astype(np.float64).T + bs.astype(np.float64)
+    got, out, hout = x.copy(), np.zeros((M, D), np.uint16), np.zeros((M, D), np.uint16)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    ms = C.c_float(0)
+    ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(x), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
+                                 P(ln_in), P(ln_out), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
+                                 P(ao), P(wp), P(bp), P(skip), P(ws), P(bs)))
+    err = np.abs(got - want)
+    scale = float(want.std())
+    rows = err.max(axis=1)
+    print(f"skip M={M} D={D} extras={extras}: max {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (x' std {scale:.3f}); worst row {int(rows.argmax())}")
+    assert np.isfinite(got).all()
+    # y carries the MLP's own error (<= 1.5e-2 of its spread, above) into a K = 2D Linear with weights of size 0.04, plus the
+    # bf16 rounding of y (a different rounding boundary than the reference's wherever y sits within that error of one)
+    assert err.max() <= 3e-2 * max(scale, 0.1) and np.sqrt((err ** 2).mean()) <= 4e-3 * max(scale, 0.1)
+    as_f32 = lambda u: torch.from_numpy(u.view(np.int16)).view(torch.bfloat16).to(torch.float32).numpy()
+    herr = np.abs(as_f32(hout).astype(np.float64) - _layernorm(got, ln_out).astype(np.float64))
+    assert herr.max() <= 4e-2 and np.sqrt((herr ** 2).mean()) <= 3e-3
 
 
 def test_fused_mlp_rows_do_not_depend_on_their_neighbours():
@@ -150,7 +196,7 @@ def test_fused_mlp_rows_do_not_depend_on_their_neighbours():
         ms = C.c_float(0)
         ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, x.shape[0], D, hidden, extras, P(x), P(w1), P(b1), P(w2), P(b2), P(got), None,
                                      P(ln), P(ln), P(hout), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
-                                     None, None, None))
+                                     None, None, None, None, None, None))
         return got, hout
 
     big, hbig = run(x_all)

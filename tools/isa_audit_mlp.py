@@ -21,7 +21,7 @@ def main():
     lines = open(out).read().split("\n")
     rc = 0
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
-    assert len(starts) == 3, "expected the plain, LayerNorm-in and LayerNorm-in + proj instantiations"
+    assert len(starts) == 4, "expected the plain, LayerNorm-in, LayerNorm-in + proj and + skip instantiations"
     for start in starts:
         end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))   # (a kernel may have several s_endpgm)
         body = lines[start:end]
@@ -41,6 +41,17 @@ def main():
                     and rep["mfma"] == 128 and rep["ds_read_b128"] == 128 + 8 and rep["lds_dma"] == 32 and rep["barrier"] == 4)
             print("  loop:", rep, "OK" if good else "FAILED")
             ok = ok and good
+        if "ELb1ELb1ELb1E" in lines[start]:
+            # SKIP instantiation: the 2 NT F MFMAs of the skip phases sit between the chunk loop and the epilogue -- straight-line
+            # code; no compiler-generated register traffic (copies, AGPR moves, spills) may sit between its MFMAs
+            mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+            last_loop_end = max(i for i, l in enumerate(body) if "s_cbranch" in l and i < mf[-1] - 1000) if any("s_cbranch" in l for l in body) else 0
+            region = [i for i in mf if i > last_loop_end]
+            tail = body[region[0]:region[-1] + 1]
+            cnt = lambda pat: sum(bool(re.search(pat, l)) for l in tail)
+            rep = {"mfma": cnt(r"v_mfma"), "ds_read_b128": cnt(r"ds_read_b128"), "lds_dma": cnt(r"global_load_lds"), "barrier": cnt(r"s_barrier"),
+                   "scratch": cnt(r"scratch_"), "accvgpr": cnt(r"v_accvgpr"), "waitcnt_vm0": cnt(r"s_waitcnt vmcnt\(0\)")}
+            print("  straight-line MFMA region after the last loop:", rep)
         total_scratch = sum("scratch_" in l for l in body)
         print(lines[start].split(":")[0][-40:], "| instructions:", sum(l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;") for l in body),
               "| scratch ops in whole kernel:", total_scratch, "| AUDIT", "OK" if ok else "FAILED")
