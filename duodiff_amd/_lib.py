@@ -14,7 +14,7 @@ DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
 DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, DD_EE_ATTENTION_PROBE = 0, 1, 2, 3
 ABI_VERSION = 2
 DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_EMBED, DD_DEV_MLP_EXTRAS_ONLY = 1, 2, 4, 8, 16
-DD_DEV_NO_FUSED_SKIP = 32
+DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV = 32, 64
 
 
 class dd_config(C.Structure):
@@ -84,7 +84,7 @@ SIGNATURES = {
     "dd_vae_destroy": (None, [C.c_void_p]),
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
-    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 6),
+    "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),
     "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
     "dd_dev_set_flags": (C.c_int, [C.c_void_p, C.c_uint]),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),

@@ -107,6 +107,8 @@ struct dd_model {
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
     bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
                                           //     whose heads read every block's output)
+    bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
+    bf16_t* qkv_dump = nullptr;           // scratch for the qkv stores of rows past the end of a ragged tile
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
@@ -394,6 +396,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     const int nb = (int)m->blocks.size();
     bool h_ready = false;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one)
     bool skip_done = false; // ... and x already holds that block's skip_linear output (the previous fused launch ran it too)
+    bool qkv_done = false;  // ... and qkv already holds that block's attn.qkv output (ditto)
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
@@ -426,13 +429,14 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
         }
         skip_done = false;
-        if (!h_ready) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
+        if (!h_ready && !qkv_done) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
         h_ready = false;
-        {
+        if (!qkv_done) {
             GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
             g.hm = make_head_major(L, m->H);     // head-major: each (q | k | v, head) unit of an image is contiguous (attention.hip)
             DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
         }
+        qkv_done = false;
         DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
         if (!(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
@@ -472,6 +476,14 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     fa.ln_out_g = wn.ln1_g; fa.ln_out_b = wn.ln1_b; fa.ln_out = (bf16_t*)h;
                     h_ready = true; skip_done = true;
                 }
+                // the next block's attn.qkv last of all (where that block's skip_linear, if it has one, runs in here as well)
+                const bool qkv_next = m->fused_qkv && bi + 1 < nb && (bi < m->half_depth || skip_next);
+                if (qkv_next) {
+                    const BlockW& wn = m->blocks[bi + 1];
+                    fa.ln_out_g = wn.ln1_g; fa.ln_out_b = wn.ln1_b; fa.ln_out = (bf16_t*)h;   // (written for the extra-token rows only)
+                    fa.qkv_out = (bf16_t*)qkv; fa.qkv_dump = m->qkv_dump; fa.hm = make_head_major(L, m->H); fa.nqkv = 3 * D / 32;
+                    h_ready = true; qkv_done = true;
+                }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
                 if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
                 if (int rc = mark()) return rc;
@@ -485,6 +497,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 } else {
                     DD_HIP(c, launch_mlp_reduce(fa, D, s));
                 }
+                if (qkv_next) DD_HIP(c, launch_qkv_rows(fa, D, s));   // the extra-token rows' qkv, from the norm1 rows the launch above wrote
                 continue;
             }
         }
@@ -773,11 +786,13 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(c->dev_flags & DD_DEV_NO_FUSED_MLP);
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
     m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
+    m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b; bool skip; };
     std::vector<BlockOff> boffs;
     // next_skip: prefix of the block whose skip_linear runs in THIS block's fused launch ("" = none)
-    auto pack_block = [&](const std::string& p, bool skip, const std::string& next_skip) {
+    // next_qkv: prefix of the block whose attn.qkv runs in THIS block's fused launch ("" = none: the last block)
+    auto pack_block = [&](const std::string& p, bool skip, const std::string& next_skip, const std::string& next_qkv) {
         BlockOff o{};
         o.skip = skip;
         o.ln1_g = put_f32(P(p + "norm1.weight").data(), D); o.ln1_b = put_f32(P(p + "norm1.bias").data(), D);
@@ -790,7 +805,8 @@ int dd_model_finalize(dd_model* m, int precision) {
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
         if (m->fused_mlp) {
             const bool with_skip = m->fused_skip && !next_skip.empty();
-            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj, with_skip));
+            const bool with_qkv = m->fused_qkv && !next_qkv.empty() && (next_skip.empty() || with_skip);   // (an out-block's qkv needs its skip_linear in here too)
+            o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj, with_skip, with_qkv));
             o.mlp_b1p = put_raw((size_t)hid * 4);
             const size_t proj_bytes = m->fused_proj ? (size_t)D * D * 2 : 0;      // D/32 blocks of Wproj lead the stream
             if (m->fused_proj) mlp_fused_pack_proj(D, P(p + "attn.proj.weight").data(), host_f2bf, (unsigned short*)&host[o.mlp_img]);
@@ -799,13 +815,18 @@ int dd_model_finalize(dd_model* m, int precision) {
             if (with_skip)    // the next block's skip_linear: 2 D/32 blocks behind the MLP blocks
                 mlp_fused_pack_skip(D, P(next_skip + "skip_linear.weight").data(), host_f2bf,
                                     (unsigned short*)&host[o.mlp_img + proj_bytes + (size_t)(hid / 32) * 2 * (D / 16) * 1024]);
+            if (with_qkv)     // the next block's attn.qkv: 3 D/32 blocks closing the image
+                mlp_fused_pack_rows(D, 3 * D, P(next_qkv + "attn.qkv.weight").data(), host_f2bf,
+                                    (unsigned short*)&host[o.mlp_img + proj_bytes + ((size_t)(hid / 32) * 2 + (with_skip ? D / 16 : 0)) * (D / 16) * 1024]);
         }
         boffs.push_back(o);
     };
-    for (int i = 0; i < m->half_depth; ++i) pack_block("in_blocks." + std::to_string(i) + ".", false, "");
-    pack_block("mid_block.", false, m->half_depth > 0 ? "out_blocks.0." : "");
+    auto in_name = [&](int i) { return "in_blocks." + std::to_string(i) + "."; };
+    auto out_name = [&](int i) { return "out_blocks." + std::to_string(i) + "."; };
+    for (int i = 0; i < m->half_depth; ++i) pack_block(in_name(i), false, "", i + 1 < m->half_depth ? in_name(i + 1) : std::string("mid_block."));
+    pack_block("mid_block.", false, m->half_depth > 0 ? out_name(0) : "", m->half_depth > 0 ? out_name(0) : "");
     for (int i = 0; i < m->half_depth; ++i)
-        pack_block("out_blocks." + std::to_string(i) + ".", true, i + 1 < m->half_depth ? "out_blocks." + std::to_string(i + 1) + "." : "");
+        pack_block(out_name(i), true, i + 1 < m->half_depth ? out_name(i + 1) : "", i + 1 < m->half_depth ? out_name(i + 1) : "");
 
     // patch-embed weight [D, pd] -> transposed [pd, D] (coalesced over D in the embed kernel)
     std::vector<float> wt((size_t)m->pd * D);
@@ -933,6 +954,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_dec = take(Mp * m->pd * 4);
     const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid) : 0;
     const size_t o_part = take(part_bytes);
+    const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
     m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
@@ -940,6 +962,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     for (size_t o : o_sk) m->skips.push_back(m->wsarena + o);
     m->mlp_partial = part_bytes ? (float*)(m->wsarena + o_part) : nullptr;
     m->mlp_partial_bytes = part_bytes;
+    m->qkv_dump = m->fused_qkv ? (bf16_t*)(m->wsarena + o_dump) : nullptr;
 
     // host copies are no longer needed
     for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
@@ -1324,21 +1347,25 @@ int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float*
 int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_host, const float* w1, const float* b1, const float* w2,
                const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in, const float* ln_out,
                unsigned short* ln_out_host, int iters, void* stream, float* ms_out, const float* ao_host, const float* wproj,
-               const float* bproj, const float* skip_host, const float* wskip, const float* bskip) {
+               const float* bproj, const float* skip_host, const float* wskip, const float* bskip, const float* wqkv,
+               unsigned short* qkv_out_host) {
     const bool proj = ao_host && wproj && bproj;
     const bool skp = skip_host && wskip && bskip;
+    const bool qk = wqkv && qkv_out_host;
+    if (qk && (!proj || !ln_out || (hidden / 32) % 2)) return DD_ERR_INVALID;   // the qkv phases ride on the proj-fused launch, behind norm1
     if (proj && (!ln_in || D % 128)) return DD_ERR_INVALID;   // the projection rides in the LayerNorm-in kernel only
     if (skp && (!proj || !ln_out || !ln_out_host || (hidden / 32) % 2)) return DD_ERR_INVALID;   // the skip phases ride on the proj-fused launch and end in norm1
     if (!c || !x_host || !w1 || !b1 || !w2 || !b2 || !xres_host || M < 1 || iters < 0 || extras < 0 || (extras > 0 && M % (1 + extras))) return DD_ERR_INVALID;
     if (!mlp_fused_supported(D, hidden)) return fail(c, DD_ERR_UNSUPPORTED, "fused MLP: D in {64,128,256,512}, hidden % 64 == 0");
     hipStream_t s = (hipStream_t)stream;
     const size_t Mp = (size_t)round_up(M, 256);
-    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden, proj, skp) / 2, 0);
+    std::vector<unsigned short> xh(Mp * D, 0), img(mlp_fused_image_bytes(D, hidden, proj, skp, qk) / 2, 0);
     std::vector<float> b1p(hidden), xr(Mp * D, 0.f);
     for (size_t i = 0; i < (size_t)M * D; ++i) { xh[i] = host_f2bf(x_host[i]); xr[i] = xres_host[i]; }
     if (proj) mlp_fused_pack_proj(D, wproj, host_f2bf, img.data());
     mlp_fused_pack(D, hidden, w1, b1, w2, ln_in != nullptr, host_f2bf, img.data() + (proj ? (size_t)D * D : 0), b1p.data());
     if (skp) mlp_fused_pack_skip(D, wskip, host_f2bf, img.data() + (proj ? (size_t)D * D : 0) + (size_t)(hidden / 32) * 2 * (D / 16) * 512);
+    if (qk) mlp_fused_pack_rows(D, 3 * D, wqkv, host_f2bf, img.data() + (proj ? (size_t)D * D : 0) + ((size_t)(hidden / 32) * 2 + (skp ? D / 16 : 0)) * (D / 16) * 512);
     // extras > 0: the M rows are `M / (1 + extras)` images of one patch token each (drives the hidden-split path);
     // extras == 0: one image of M patch tokens (main tiles only)
     MlpFusedArgs a{};
@@ -1347,8 +1374,8 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     if (c->dev_flags & DD_DEV_MLP_EXTRAS_ONLY) { a.tiles_main = 0; a.n_main = 0; }   // time the hidden-split workgroups alone
     const size_t part = (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
     void *dX = nullptr, *dI = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dXr = nullptr, *dO = nullptr, *dP = nullptr, *dLn = nullptr, *dH = nullptr;
-    void *dAo = nullptr, *dBp = nullptr, *dSk = nullptr, *dBs = nullptr;
-    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dBp, dSk, dBs}) if (p) (void)hipFree(p); };
+    void *dAo = nullptr, *dBp = nullptr, *dSk = nullptr, *dBs = nullptr, *dQ = nullptr, *dQd = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dI, dB1, dB2, dXr, dO, dP, dLn, dH, dAo, dBp, dSk, dBs, dQ, dQd}) if (p) (void)hipFree(p); };
 #define DD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(c, _e, #expr); } } while (0)
     DD_TRY(hipMalloc(&dX, xh.size() * 2)); DD_TRY(hipMalloc(&dI, img.size() * 2)); DD_TRY(hipMalloc(&dB1, hidden * 4));
     DD_TRY(hipMalloc(&dB2, D * 4)); DD_TRY(hipMalloc(&dXr, xr.size() * 4)); DD_TRY(hipMalloc(&dO, xh.size() * 2));
@@ -1390,10 +1417,23 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         a.out = (bf16_t*)dO;   // y of the extra-token rows travels through the bf16 copy
         ar = a; ar.ln_out = nullptr;
     }
+    size_t qkv_elems = 0;
+    if (qk) {   // head-major qkv of the rows as images of a.tok_l tokens (HeadMajor, dd_internal.h): [images][3 D / 64 units][Lp][64]
+        a.hm = make_head_major(a.tok_l, D / 64);
+        const size_t images = (size_t)(M / a.tok_l);
+        qkv_elems = images * 3 * D * (size_t)a.hm.Lp;
+        DD_TRY(hipMalloc(&dQ, qkv_elems * 2)); DD_TRY(hipMalloc(&dQd, 16384));
+        DD_TRY(hipMemset(dQ, 0, qkv_elems * 2));
+        a.qkv_out = (bf16_t*)dQ; a.qkv_dump = (bf16_t*)dQd; a.nqkv = 3 * D / 32;
+        ar.qkv_out = a.qkv_out; ar.qkv_dump = a.qkv_dump; ar.nqkv = a.nqkv; ar.hm = a.hm;
+        if (!skp) ar = a;
+    }
     DD_TRY(launch_mlp_fused(a, D, s));
     DD_TRY(launch_mlp_reduce(ar, D, s));
     DD_TRY(launch_skip_rows_ln(a, D, s));
+    DD_TRY(launch_qkv_rows(a, D, s));
     DD_TRY(hipStreamSynchronize(s));
+    if (qk) DD_TRY(hipMemcpy(qkv_out_host, dQ, qkv_elems * 2, hipMemcpyDeviceToHost));
     DD_TRY(hipMemcpy(xres_host, dXr, (size_t)M * D * 4, hipMemcpyDeviceToHost));
     if (out_host) DD_TRY(hipMemcpy(out_host, dO, (size_t)M * D * 2, hipMemcpyDeviceToHost));
     if (a.ln_out) DD_TRY(hipMemcpy(ln_out_host, dH, (size_t)M * D * 2, hipMemcpyDeviceToHost));
@@ -1401,7 +1441,7 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         hipEvent_t e0 = nullptr, e1 = nullptr;
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(ar, D, s)); DD_TRY(launch_skip_rows_ln(a, D, s)); }
+        for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(ar, D, s)); DD_TRY(launch_skip_rows_ln(a, D, s)); DD_TRY(launch_qkv_rows(a, D, s)); }
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -109,6 +109,10 @@ struct MlpFusedArgs {
     const bf16_t* skip;    // nskip > 0: the NEXT block's skip_linear runs behind the MLP (main tiles): x' = [y | skip] . Wskip^T + bskip
     const float* bskip;    //            replaces y in xres, ln_out = norm1(x'); skip = the long-skip operand's rows [Mp, D]
     int nskip;             // 2 * D / 32 blocks of Wskip behind the MLP blocks of wimg (mlp_fused_pack_skip), or 0
+    bf16_t* qkv_out;       // nqkv > 0: the NEXT block's attn.qkv (no bias) runs last (main tiles): qkv = norm1(updated rows) . Wqkv^T, written
+    bf16_t* qkv_dump;      //           head-major (hm) -- norm1 is then NOT written for the main rows; qkv_dump: 16 KB scratch (qkv | x | bf16 copy of rows past the end)
+    HeadMajor hm;          //           (stores of rows past the end of a ragged tile)
+    int nqkv;              // 3 * D / 32 blocks of Wqkv closing the image (mlp_fused_pack_rows), or 0
     const float* ln_out_g; // with ln_out: LayerNorm of the UPDATED rows, written as bf16 [Mp, D] (next block's norm1)
     const float* ln_out_b;
     bf16_t* ln_out;
@@ -126,7 +130,11 @@ struct MlpFusedArgs {
     int tiles_main, tiles_left, groups, cpg;
 };
 bool mlp_fused_supported(int D, int hidden);
-size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip);
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip, bool with_qkv);
+// nn.Linear weight [nrows, D] -> nrows / 32 blocks (one 32-row tile each, fragment f = k-step f, k index in accumulator order)
+void mlp_fused_pack_rows(int D, int nrows, const float* w, unsigned short (*to_bf16)(float), unsigned short* img);
+// qkv of the extra-token rows of a QKV launch (from a.ln_out, which the reduce / skip_rows launch has written for them)
+hipError_t launch_qkv_rows(const MlpFusedArgs& a, int D, hipStream_t s);
 void mlp_fused_pack_proj(int D, const float* wp, unsigned short (*to_bf16)(float), unsigned short* img);
 void mlp_fused_pack_skip(int D, const float* ws, unsigned short (*to_bf16)(float), unsigned short* img);
 hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s);

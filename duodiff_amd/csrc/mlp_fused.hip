@@ -160,6 +160,18 @@ __device__ __forceinline__ void gap_plain(f32x16& acc, bf16x8& wa, const bf16x8&
     }
 }
 
+// the same with the accumulator in VGPRs (the QKV phases: the tile is converted and stored by VALU code)
+template <int LG, bool READ, int LO>
+__device__ __forceinline__ void gap_plain_v(f32x16& acc, bf16x8& wa, const bf16x8& xb, unsigned la) {
+    if constexpr (LG >= 0) {
+        if constexpr (READ) asm volatile(DD_S_MFMA_W DD_S_READ : [acc] "+v"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [la] "v"(la), [lg] "i"(LG), [lo] "i"(LO));
+        else asm volatile(DD_S_MFMA_W : [acc] "+v"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [lg] "i"(LG));
+    } else {
+        if constexpr (READ) asm volatile(DD_S_MFMA_N DD_S_READ : [acc] "+v"(acc), [wa] "+v"(wa) : [xb] "v"(xb), [la] "v"(la), [lo] "i"(LO));
+        else asm volatile(DD_S_MFMA_N : [acc] "+v"(acc), [wa] "+v"(wa) : [xb] "v"(xb));
+    }
+}
+
 // the same GELU pieces as statements of their own (D < 512: several pieces per gap)
 template <int K>
 __device__ __forceinline__ void gelu_piece(float va, float vb, const GeluConst& k, GeluPair& r, unsigned& out) {
@@ -184,6 +196,19 @@ __device__ __forceinline__ void load_quad_agpr(f32x4& q, const float* p) {
 // Pin an accumulator tile to its AGPRs at this point of the program: hipcc treats the tile as rewritten, so VGPR copies
 // made for the LayerNorm / epilogue arithmetic die here instead of piling up (256 live values would spill to scratch).
 __device__ __forceinline__ void acc_pin(f32x16& y) { asm volatile("" : "+a"(y)); }
+
+// ... all tiles of a wave in ONE statement (asm operand lists take no pack expansion)
+template <int NT>
+__device__ __forceinline__ void pin_tiles(f32x16 (&y)[NT]) {
+    static_assert(NT == 2 || NT == 4 || NT == 8 || NT == 16, "D in {64, 128, 256, 512}");
+    if constexpr (NT == 2) asm volatile("" : "+a"(y[0]), "+a"(y[1]));
+    else if constexpr (NT == 4) asm volatile("" : "+a"(y[0]), "+a"(y[1]), "+a"(y[2]), "+a"(y[3]));
+    else if constexpr (NT == 8)
+        asm volatile("" : "+a"(y[0]), "+a"(y[1]), "+a"(y[2]), "+a"(y[3]), "+a"(y[4]), "+a"(y[5]), "+a"(y[6]), "+a"(y[7]));
+    else
+        asm volatile("" : "+a"(y[0]), "+a"(y[1]), "+a"(y[2]), "+a"(y[3]), "+a"(y[4]), "+a"(y[5]), "+a"(y[6]), "+a"(y[7]), "+a"(y[8]),
+                     "+a"(y[9]), "+a"(y[10]), "+a"(y[11]), "+a"(y[12]), "+a"(y[13]), "+a"(y[14]), "+a"(y[15]));
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -236,11 +261,18 @@ struct MlpCfg {
 // MLP blocks in the image: NT blocks of the y half (one column tile x all its k-steps each), then the long-skip operand's
 // half in two passes of NT/2 blocks (two column tiles x half the k-steps each) -- the operand's rows are fetched half at
 // a time into registers that are free at that point, each half a pass ahead of its use.
-template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false>
+// QKV (main tiles of a PROJ launch): the NEXT block's attn.qkv Linear (no bias) runs behind everything else -- its input
+// norm1(x) never leaves the registers.  Order at the end of the launch: LayerNorm statistics from the accumulators, norm1
+// straight into MFMA B fragments, 3D/32 phases (one 32-column tile of q | k | v each, weights streamed through the ring like
+// every other block: the qkv blocks close the image) into two alternating VGPR accumulators -- tile t-1 is converted to bf16
+// and stored (head-major, 64 contiguous bytes per row and phase) in the second half of phase t, so 100 MB of qkv leave the
+// chip under MFMA work -- and only then the fp32 rows x (and their bf16 copy) are stored.
+template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false, bool QKV = false>
 __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
     static_assert(!PROJ || (LNIN && !PARTIAL && C::NT % 4 == 0), "proj fusion: main tiles of the LayerNorm-in kernel, D % 128 == 0");
     static_assert(!SKIP || PROJ, "skip fusion rides on the proj-fused main tiles");
+    static_assert(!QKV || PROJ, "qkv fusion rides on the proj-fused main tiles");
     float* b1s = reinterpret_cast<float*>(smem + C::RING);           // [hidden + 32], in accumulator-register order per chunk
     float* vecs = b1s + (a.nchunks + 1) * 32;                        // 7 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2 | bproj | bskip
     // weight stream: [nproj blocks of Wproj][W1(0) W2(0) W1(1) W2(1) ...]; stream position p lives in ring slot p & 3
@@ -742,11 +774,15 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     } else {
         bool row_ok;
         const long long row = row_of(row_ok);
-        if (!row_ok) return;     // rows past the end of a ragged last tile (both lanes of a row agree; no barrier follows)
+        if constexpr (!QKV) {
+            if (!row_ok) return; // rows past the end of a ragged last tile (both lanes of a row agree; no barrier follows)
+        }
         const float* lg_out = vecs + 2 * D + 4 * he;
         const float* lb_out = vecs + 3 * D + 4 * he;
         const float* lb2 = vecs + 4 * D + 4 * he;
-        float* xrow = a.xres + row * D + 4 * he;
+        // QKV: every wave runs the phases below, so rows past the end of a ragged tile store into the dump area instead of leaving
+        float* xrow = (!QKV || row_ok) ? a.xres + row * D + 4 * he : reinterpret_cast<float*>(reinterpret_cast<char*>(a.qkv_dump) + 8192) + 4 * he;
+        bf16_t* orow = (!QKV || row_ok) ? a.out + row * a.ldo + 8 * he : reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(a.qkv_dump) + 12288) + 8 * he;
         f32x4 xl[2][4];   // !LNIN: residual quads of tile t, loaded one tile ahead of the stores (vmcnt retires in order)
         if constexpr (!LNIN) {
 #pragma unroll
@@ -783,7 +819,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                     const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
                     const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    *reinterpret_cast<uint4*>(a.out + row * a.ldo + 32 * t + 8 * gp + 8 * he) = o;
+                    *reinterpret_cast<uint4*>(orow + 32 * t + 8 * gp) = o;
                 }
             }
             acc_pin(Y[t]);                       // the copy dies here: the LayerNorm pass below re-reads the accumulators instead of a spill slot
@@ -791,7 +827,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                                                      // branch below and keeps -- spills -- all 256 row values for it)
             __builtin_amdgcn_sched_barrier(0);   // tile by tile: keeps the live set small (no spills)
         }
-        if (LNIN && a.ln_out) {   // LayerNorm of the updated row (the next block's norm1) as bf16, from the registers (LNIN mode only)
+        if (QKV || (LNIN && a.ln_out)) {   // LayerNorm of the updated row (the next block's norm1), from the registers (LNIN mode only): stored as
+                                           // bf16 -- or (QKV) kept as the B fragments of the qkv phases below (accumulator k order)
             float mean, rstd;
             ln_stats_shifted<D>(cshift, (s4[0] + s4[1]) + (s4[2] + s4[3]), (q4[0] + q4[1]) + (q4[2] + q4[3]), mean, rstd);
             const float shift = -mean * rstd;
@@ -810,15 +847,107 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                     const f32x4 w = (q * rstd + shift) * gv + bv;
                     v[g] = uint2{pack2(w[0], w[1]), pack2(w[2], w[3])};
                 }
+                if constexpr (QKV) {
+                    // k-step 2t + kq of the qkv product = quads 2kq, 2kq + 1 of tile t (as norm2 feeds fc1 in the prologue)
+                    xf[2 * t] = __builtin_bit_cast(bf16x8, u32x4{v[0].x, v[0].y, v[1].x, v[1].y});
+                    xf[2 * t + 1] = __builtin_bit_cast(bf16x8, u32x4{v[2].x, v[2].y, v[3].x, v[3].y});
+                    asm volatile("" : "+v"(xf[2 * t]), "+v"(xf[2 * t + 1]));   // computed HERE (hipcc otherwise sinks the arithmetic to the first use
+                                                                               // in the phases and keeps -- spills -- every LDS quad loaded for it)
+                    acc_pin(Y[t]);
+                } else {
 #pragma unroll
-                for (int gp2 = 0; gp2 < 4; gp2 += 2) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp2].x, v[gp2 + 1].x, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp2].y, v[gp2 + 1].y, false, false);
-                    const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                    *reinterpret_cast<uint4*>(a.ln_out + row * D + 32 * t + 8 * gp2 + 8 * he) = o;
+                    for (int gp2 = 0; gp2 < 4; gp2 += 2) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp2].x, v[gp2 + 1].x, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp2].y, v[gp2 + 1].y, false, false);
+                        const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        *reinterpret_cast<uint4*>(a.ln_out + row * D + 32 * t + 8 * gp2 + 8 * he) = o;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+
+        if constexpr (QKV) {
+            // ---- the qkv phases.  The row accumulators are dead from here on (x has been stored above: its stores drain under the
+            // first phases -- vmcnt is in order, so the first request that must be confirmed behind them waits for them).  Stream
+            // position of qkv block t: behind the MLP (and skip) blocks, slot t & 3; blocks 0..2 were requested by the run-ahead of the
+            // loop before and have landed (wait_vmcnt<0> + the barrier here).
+            const char* const wqkv = wmlp + ((size_t)2 * a.nchunks + (SKIP ? 2 * C::NT : 0)) * C::BLK;
+            const unsigned lds_lo_q = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
+            const unsigned lds_hi_q = lds_lo_q + 65536u;
+            constexpr int PDq = C::F / 2 < 8 ? C::F / 2 : 8;
+            constexpr int NQ = 3 * C::NT, NGq = NQ * C::F;
+            // this lane's row in the head-major qkv tensor (dd_internal.h HeadMajor): unit u = t / 2 is Lp rows of 128 bytes further per step;
+            // rows past the end of a ragged tile write to a dump area (every wave issues the same number of stores: the waits count them)
+            const int pidx = (int)(row / a.tok_l), lidx = (int)(row - (long long)pidx * a.tok_l);
+            char* qrow = row_ok ? reinterpret_cast<char*>(a.qkv_out) + (((long long)pidx * (3 * a.hm.H)) * a.hm.Lp + lidx) * 128 + 16 * he
+                                : reinterpret_cast<char*>(a.qkv_dump) + (tid * 2) * 16;
+            const long long ustride = row_ok ? (long long)a.hm.Lp * 128 : 0;    // bytes between consecutive (q | k | v, head) units of an image
+            const int tstride = row_ok ? 64 : 0, gstride = row_ok ? 32 : 16;    // bytes between the two tiles of a unit / the two 16-byte pieces of a tile
+            // the x / bf16-copy stores above are in the vector-memory queue in front of everything the phases issue: the counted
+            // waits below only ever ask for requests issued INSIDE the phases, so older stores need no accounting
+            __builtin_amdgcn_s_barrier();
+            bf16x8 wq2[PDq];
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                (lds_frag<J * 1024>(wq2[J], lds_lo_q), ...);
+            }(std::make_integer_sequence<int, PDq>{});
+            f32x16 qa, qb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { qa[e] = 0.f; qb[e] = 0.f; }
+            asm volatile("" : "+a"(qa), "+a"(qb));
+            // tile tt (in acc) -> bf16, two 16-byte stores per lane (v_permlane32_swap pairs the lane halves), accumulator back to zero
+            auto flush_tile = [&](int tt, f32x16& acc) {
+                uint2 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = uint2{pack2(acc[4 * g], acc[4 * g + 1]), pack2(acc[4 * g + 2], acc[4 * g + 3])};
+                char* dst = qrow + (long long)(tt >> 1) * ustride + (tt & 1) * tstride;
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
+                    const unsigned o0 = s0[0], o1 = s1[0], o2 = s0[1], o3 = s1[1];
+                    *reinterpret_cast<uint4*>(dst + (gp >> 1) * gstride) = uint4{o0, o1, o2, o3};
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            };
+            [&]<int... GI>(std::integer_sequence<int, GI...>) {
+                ([&] {
+                    constexpr int g = GI, t = g / C::F, f = g % C::F;
+                    if constexpr (f == C::F / 2) {
+                        // younger than block t+1's requests (issued in the middle of phase t-2): the two stores of phase t-2 (tile t-3, if
+                        // any), block t+2's requests, the two stores of phase t-1 (tile t-2, if any)
+                        constexpr int younger = C::FPW + (t - 2 >= 1 ? 2 : 0) + (t - 1 >= 1 ? 2 : 0);
+                        if constexpr (t >= 2) wait_vmcnt<younger>();
+                        __builtin_amdgcn_s_barrier();
+                        const char* src = uniform_ptr(wqkv + (size_t)(t + 3) * C::BLK);
+                        char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
+                        [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
+                    }
+                    if constexpr (f == C::F / 2 + 1 && t >= 1) {       // second half of phase t: tile t-1 leaves (its last MFMA is F/2 + 1 gaps old)
+                        asm volatile("" ::: "memory");
+                        if constexpr ((t - 1) & 1) { asm volatile("" : "+a"(qb)); flush_tile(t - 1, qb); }
+                        else { asm volatile("" : "+a"(qa)); flush_tile(t - 1, qa); }
+                    }
+                    if constexpr (f == C::F - 2 && t >= 1) {           // ... and is zero again before phase t+1 accumulates into it
+                        if constexpr ((t - 1) & 1) asm volatile("" : "+a"(qb) :: "memory");
+                        else asm volatile("" : "+a"(qa) :: "memory");
+                    }
+                    constexpr int gn = g + PDq, left = NGq - 1 - g;
+                    constexpr int lg_self = left < PDq - 1 ? left : PDq - 1, lg_next = left - 1 < PDq - 1 ? left - 1 : PDq - 1;
+                    constexpr int LG = (g & 1) ? -1 : (left >= 1 ? lg_next - (left >= PDq ? 1 : 0) : lg_self);
+                    constexpr bool RD = gn < NGq;
+                    constexpr int LO = RD ? ((gn / C::F) & 3) * C::BLK + (gn % C::F) * 1024 : 0;
+                    constexpr int LOA = LO < 65536 ? LO : LO - 65536;
+                    if constexpr (t & 1) gap_plain<LG, RD, LOA>(qb, wq2[g % PDq], xf[f], LO < 65536 ? lds_lo_q : lds_hi_q);
+                    else gap_plain<LG, RD, LOA>(qa, wq2[g % PDq], xf[f], LO < 65536 ? lds_lo_q : lds_hi_q);
+                }(), ...);
+            }(std::make_integer_sequence<int, NGq>{});
+            mfma_drain();
+            if constexpr ((NQ - 1) & 1) { asm volatile("" : "+a"(qb)); flush_tile(NQ - 1, qb); }
+            else { asm volatile("" : "+a"(qa)); flush_tile(NQ - 1, qa); }
+            asm volatile("" : "+a"(qa), "+a"(qb));
+            wait_vmcnt<0>();     // the run-ahead requests of the padded blocks must not outlive the workgroup's LDS allocation
         }
     }
 }
@@ -832,11 +961,11 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 // Either way an optional second LayerNorm (the NEXT block's norm1, models/uvit.py:206) of the updated rows is written
 // as bf16 from the epilogue (a.ln_out), so neither LayerNorm of a block needs a launch or an HBM round trip of x.
 // Workgroups [0, tiles_main) take a main tile each; the rest are the hidden-split workgroups of the extra-token tiles.
-template <int D, bool LNIN, bool PROJ, bool SKIP = false>
+template <int D, bool LNIN, bool PROJ, bool SKIP = false, bool QKV = false>
 __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.tiles_main) {
-        mlp_body<D, LNIN, false, PROJ, SKIP>(a, smem, blockIdx.x, 0, a.nchunks, 0);
+        mlp_body<D, LNIN, false, PROJ, SKIP, QKV>(a, smem, blockIdx.x, 0, a.nchunks, 0);
     } else {
         const int e = blockIdx.x - a.tiles_main;
         const int lt = e / a.groups, g = e - lt * a.groups;
@@ -1080,15 +1209,70 @@ __global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs 
     }
 }
 
+// qkv of the extra-token rows of a QKV launch: out[row, 32t .. 32t+31] = norm1(x)[row] . Wqkv[32t ..]^T from the bf16 LayerNorm rows
+// the reduce / skip_rows launch wrote (a.ln_out), head-major stores.  Workgroup t = one 32-column tile of 128 rows (a 32-row
+// group per wave), like proj_rows_kernel: every load up front, whole rows into a wave-private LDS strip, weights from the
+// image's fragment order (accumulator k order: the row fragments are gathered as two 8-byte pieces per k-step).
+template <int D>
+__global__ void __launch_bounds__(256) qkv_rows_kernel(const MlpFusedArgs a) {
+    using C = MlpCfg<D>;
+    constexpr int LPR = D / 8, RPI = 64 / LPR, NI = 32 / RPI, IPITCH = 1024 + 32;
+    extern __shared__ __attribute__((aligned(16))) char strip_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int t = blockIdx.x, idx0 = blockIdx.y * 128 + wave * 32;
+    char* strip = strip_lds + wave * (NI * IPITCH);
+    auto row_of = [&](int idx) -> long long {
+        const int q = idx < a.n_extra ? idx : a.n_extra - 1, b = q / a.tok_e;
+        return (long long)b * a.tok_l + (q - b * a.tok_e);
+    };
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        glds16(a.ln_out + row_of(idx0 + i * RPI + lane / LPR) * D + (lane % LPR) * 8, strip + i * IPITCH);
+    __builtin_amdgcn_sched_barrier(0);
+    const int idx = idx0 + (lane & 31);
+    const bool ok = idx < a.n_extra;
+    const long long row = row_of(idx);
+    const size_t pos = (size_t)a.nproj + 2 * (size_t)a.nchunks + (size_t)a.nskip;
+    const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wimg + (pos + t) * C::BLK) + lane;
+    bf16x8 wf[C::F];
+#pragma unroll
+    for (int ks = 0; ks < C::F; ++ks) wf[ks] = wb[ks * 64];
+    wait_vmcnt<0>();
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const char* my = strip + ((lane & 31) / RPI) * IPITCH + ((lane & 31) % RPI) * (D * 2) + 8 * h;
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C::F; ks += 2) {
+        const u32x2 l0 = *reinterpret_cast<const u32x2*>(my + 32 * ks), h0 = *reinterpret_cast<const u32x2*>(my + 32 * ks + 16);
+        const u32x2 l1 = *reinterpret_cast<const u32x2*>(my + 32 * ks + 32), h1 = *reinterpret_cast<const u32x2*>(my + 32 * ks + 48);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], h0[0], h0[1]}), acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks + 1], __builtin_bit_cast(bf16x8, u32x4{l1[0], l1[1], h1[0], h1[1]}), acc1, 0, 0, 0);
+    }
+    acc += acc1;
+    if (!ok) return;
+    bf16_t* dst = a.qkv_out + hm_offset(a.hm, (int)row, 32 * t) + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<uint2*>(dst + 8 * g) = uint2{pack2(acc[4 * g], acc[4 * g + 1]), pack2(acc[4 * g + 2], acc[4 * g + 3])};
+}
+
 template <int D>
 hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     const size_t lds = MlpCfg<D>::RING + (size_t)(a.nchunks + 1) * 32 * sizeof(float) + 7 * D * sizeof(float);   // ring | bias table (+ one chunk: bias_init(c1) is read, unused) | 7 column vectors
     const int grid = a.tiles_main + a.tiles_left * a.groups;
-    if (a.nskip > 0 && (a.nproj <= 0 || a.nskip != D / 16 || !a.skip || !a.bskip || !a.ln_out || a.nchunks % 2)) return hipErrorInvalidValue;
+    if (a.nskip > 0 && (a.nproj <= 0 || a.nskip != D / 16 || !a.skip || !a.bskip || (!a.ln_out && a.nqkv <= 0) || a.nchunks % 2)) return hipErrorInvalidValue;
+    if (a.nqkv > 0 && a.nproj <= 0) return hipErrorInvalidValue;
     if (a.nproj > 0) {
         if constexpr (D % 128 == 0) {
             if (!a.ln_in_g || !a.ao || !a.bproj || a.nproj != D / 32) return hipErrorInvalidValue;
-            if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+            if (a.nqkv > 0) {
+                if (a.nqkv != 3 * D / 32 || !a.qkv_out || !a.qkv_dump || !a.ln_out_g || !a.ln_out_b || a.hm.L != a.tok_l || a.nchunks % 2) return hipErrorInvalidValue;
+                if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, false, true>), dim3(grid), dim3(256), lds, s, a);
+            } else if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true>), dim3(grid), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((mlp_fused_kernel<D, true, true>), dim3(grid), dim3(256), lds, s, a);
         } else {
             return hipErrorInvalidValue;
@@ -1118,8 +1302,19 @@ bool mlp_fused_supported(int D, int hidden) {
 }
 
 // + four blocks: the kernel's DMA runs up to three blocks past the last chunk (branch-free pipeline); never used as data
-size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip) {
-    return ((size_t)(hidden / 32 + 2) * 2 + (with_proj ? D / 32 : 0) + (with_skip ? D / 16 : 0)) * (D / 16) * 1024;
+size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip, bool with_qkv) {
+    return ((size_t)(hidden / 32 + 2) * 2 + (with_proj ? D / 32 : 0) + (with_skip ? D / 16 : 0) + (with_qkv ? 3 * D / 32 : 0)) * (D / 16) * 1024;
+}
+
+void mlp_fused_pack_rows(int D, int nrows, const float* w, unsigned short (*to_bf16)(float), unsigned short* img) {
+    const int F = D / 16;
+    for (int t = 0; t < nrows / 32; ++t)
+        for (int f = 0; f < F; ++f)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, h = lane >> 5;
+                for (int j = 0; j < 8; ++j)
+                    img[((size_t)t * F + f) * 512 + lane * 8 + j] = to_bf16(w[(size_t)(32 * t + r) * D + 16 * f + 8 * (j >> 2) + 4 * h + (j & 3)]);
+            }
 }
 
 // skip_linear weight [D, 2D] (nn.Linear layout; input = cat([x, skip]), reference models/uvit.py:199) -> the 2 NT blocks the
@@ -1228,12 +1423,20 @@ hipError_t init_mlp_fused_kernels() {
         if (e == hipSuccess)                                                                                 \
             e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     MlpCfg<DV>::RING + bias);                                                \
+        if (e == hipSuccess)                                                                                 \
+            e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    MlpCfg<DV>::RING + bias);                                                \
+        if (e == hipSuccess)                                                                                 \
+            e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    MlpCfg<DV>::RING + bias);                                                \
     }
     DD_ATTR(64) DD_ATTR(128) DD_ATTR(256) DD_ATTR(512)
 #undef DD_ATTR
 #define DD_ATTR_P(DV)                                                                                        \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)proj_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds); \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void*)qkv_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds); \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(DV));
     DD_ATTR_P(128) DD_ATTR_P(256) DD_ATTR_P(512)
@@ -1265,6 +1468,19 @@ hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s) {
         case 128: hipLaunchKernelGGL((skip_rows_ln_kernel<128>), grid, dim3(256), lds, s, a); break;
         case 256: hipLaunchKernelGGL((skip_rows_ln_kernel<256>), grid, dim3(512), lds, s, a); break;
         case 512: hipLaunchKernelGGL((skip_rows_ln_kernel<512>), grid, dim3(1024), lds, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_qkv_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
+    if (a.n_extra <= 0 || a.nqkv <= 0) return hipSuccess;
+    if (!a.ln_out || !a.qkv_out || a.nqkv != 3 * D / 32) return hipErrorInvalidValue;
+    const dim3 grid(a.nqkv, (a.n_extra + 127) / 128);
+    switch (D) {
+        case 128: hipLaunchKernelGGL((qkv_rows_kernel<128>), grid, dim3(256), kProjRowsLds, s, a); break;
+        case 256: hipLaunchKernelGGL((qkv_rows_kernel<256>), grid, dim3(256), kProjRowsLds, s, a); break;
+        case 512: hipLaunchKernelGGL((qkv_rows_kernel<512>), grid, dim3(256), kProjRowsLds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -22,12 +22,15 @@ extern "C" {
  * launches for them).
  * skip_host [M, D] + wskip [D, 2D] + bskip [D] or NULL (needs the projection and ln_out): the NEXT block's skip_linear runs
  * behind the MLP in the same launch -- xres_host then receives x' = cat([y, skip]) . wskip^T + bskip instead of y, and
- * ln_out_host its LayerNorm (models/uvit.py:196-200, 206). */
+ * ln_out_host its LayerNorm (models/uvit.py:196-200, 206).
+ * wqkv [3D, D] + qkv_out_host (bf16, HEAD-MAJOR: [M / L images][3 D / 64 units][Lp = L rounded up to 8][64], L = M for
+ * extras == 0, else 1 + extras) or NULL (needs the projection and ln_out): the NEXT block's attn.qkv runs last in the same
+ * launch on norm1 of the updated rows (models/uvit.py:152); ln_out_host is then only written for the extra-token rows. */
 int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h_host, const float* w1, const float* b1,
                const float* w2, const float* b2, float* xres_host, unsigned short* out_host, const float* ln_in,
                const float* ln_out, unsigned short* ln_out_host, int iters, void* stream, float* ms_out,
                const float* ao_host, const float* wproj, const float* bproj, const float* skip_host, const float* wskip,
-               const float* bskip);
+               const float* bskip, const float* wqkv, unsigned short* qkv_out_host);
 
 /* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
  * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
@@ -36,6 +39,7 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
 #define DD_DEV_NO_FUSED_PROJ 2u     /* keep attn.proj as its own GEMM */
 #define DD_DEV_NO_FUSED_HEAD 4u     /* keep final LayerNorm + decoder_pred as two launches */
 #define DD_DEV_NO_FUSED_SKIP 32u    /* keep skip_linear as its own GEMM + LayerNorm launch */
+#define DD_DEV_NO_FUSED_QKV 64u     /* keep attn.qkv as its own GEMM launch */
 #define DD_DEV_GENERIC_EMBED 8u     /* generic VALU patch-embed kernel */
 #define DD_DEV_MLP_EXTRAS_ONLY 16u  /* dd_dev_mlp: launch the hidden-split (extra-token) workgroups alone */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);

@@ -21,7 +21,7 @@ def main():
     lines = open(out).read().split("\n")
     rc = 0
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
-    assert len(starts) == 4, "expected the plain, LayerNorm-in, LayerNorm-in + proj and + skip instantiations"
+    assert len(starts) == 6, "expected the plain, LayerNorm-in, + proj, + skip, + qkv and + skip + qkv instantiations"
     for start in starts:
         end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))   # (a kernel may have several s_endpgm)
         body = lines[start:end]
@@ -41,8 +41,8 @@ def main():
                     and rep["mfma"] == 128 and rep["ds_read_b128"] == 128 + 8 and rep["lds_dma"] == 32 and rep["barrier"] == 4)
             print("  loop:", rep, "OK" if good else "FAILED")
             ok = ok and good
-        if "ELb1ELb1ELb1E" in lines[start]:
-            # SKIP instantiation: the 2 NT F MFMAs of the skip phases sit between the chunk loop and the epilogue -- straight-line
+        if "ELb1ELb1ELb1E" in lines[start] or "ELb1ELb1ELb0ELb1E" in lines[start]:
+            # SKIP / QKV instantiations: the MFMAs of the skip / qkv phases sit behind the chunk loop -- straight-line
             # code; no compiler-generated register traffic (copies, AGPR moves, spills) may sit between its MFMAs
             mf = [i for i, l in enumerate(body) if "v_mfma" in l]
             last_loop_end = max(i for i, l in enumerate(body) if "s_cbranch" in l and i < mf[-1] - 1000) if any("s_cbranch" in l for l in body) else 0

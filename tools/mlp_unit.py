@@ -64,7 +64,7 @@ def run(ctx, M, D, hidden, seed=0, iters=0, extras=0, ln=False, proj=False):
     ctx.check(ctx.lib.dd_dev_mlp(ctx.handle, M, D, hidden, extras, P(h), P(w1), P(b1), P(w2), P(b2), P(got), P(out),
                                  P(ln_in) if ln else None, P(ln_out) if ln else None, P(hout) if ln else None, iters,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ms),
-                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None, None, None, None))
+                                 P(ao) if proj else None, P(wp) if proj else None, P(bp) if proj else None, None, None, None, None, None))
     if ln:
         hb = torch.from_numpy(hout.view(np.int16)).view(torch.bfloat16).to(torch.float32).numpy()
         print(f"   ln_out: max|h' - LayerNorm(x')| = {np.abs(hb - layernorm(want, ln_out)).max():.3e}")
