@@ -84,6 +84,8 @@ SIGNATURES = {
     "dd_vae_destroy": (None, [C.c_void_p]),
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "dd_dev_qkv_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),
     "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
     "dd_dev_set_flags": (C.c_int, [C.c_void_p, C.c_uint]),

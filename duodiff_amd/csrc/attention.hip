@@ -52,6 +52,193 @@ template <> struct AttnLayout<float> {
     static constexpr int kVBytes = kHD * kRowV;
 };
 
+// One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
+// O^T (two 32(d) x 32(q) tiles), the chunk's running max and the sum of exponentials.
+template <typename T, int NKT, int NT, bool KPERM, typename TileFn>
+__device__ __forceinline__ void attend_tiles(const char* Ks, const char* Vt, int L, int nkt, int lane, TileFn&& tile,
+                                         const f32x4 (&qcur)[sizeof(T) == 2 ? 4 : 8], f32x16 (&o)[2], float& mx, float& sum) {
+    using Lay = AttnLayout<T>;
+    const int half = lane >> 5, r32 = lane & 31;
+    // ---- S^T = K . Q^T, tiles of 32 keys x 32 queries
+    // (accumulators start from a literal zero C operand in the first MFMA of a tile: a separate zero-fill is 16 v_mov per
+    // tile -- 176 issue slots per chunk in a kernel that is bound by vector issue, not by the matrix pipe)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[NT];
+
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 qf[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
+        // K fragments double-buffered: tile k+1's four ds_read_b128 are issued before tile k's MFMAs, so the LDS latency
+        // hides under them (the plain read -> wait -> MFMA chain spent most of a chunk in s_waitcnt lgkmcnt)
+        auto load_k = [&](int t, bf16x8 (&kf)[4]) {
+            const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
+            const int sw = (r32 >> 1) & 7;                         // (32 t contributes 0 to (row >> 1) & 7)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                // KPERM: the 64 d of a K row sit in accumulator order (qkv_attention_kernel writes them from its accumulators):
+                // k-step st = (d tile st >> 1, register half st & 1) reads chunk 4 (st >> 1) + 2 half + (st & 1)
+                const int ch = KPERM ? 4 * (st >> 1) + 2 * half + (st & 1) : 2 * st + half;
+                kf[st] = *reinterpret_cast<const bf16x8*>(kr + ((ch ^ sw) << 4));
+            }
+        };
+        bf16x8 kfa[4], kfb[4];
+        if (tile(0) >= 0) load_k(tile(0), kfa);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int t = tile(k);
+            const int tn = k + 1 < NT ? tile(k + 1) : -1;
+            if (tn >= 0) { if (k & 1) load_k(tn, kfa); else load_k(tn, kfb); }
+            __builtin_amdgcn_sched_barrier(0);  // the look-ahead reads go out BEFORE this tile's MFMAs
+            if (t >= 0) {
+                s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[0] : kfa[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+                for (int st = 1; st < 4; ++st)
+                    s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[st] : kfa[st], qf[st], s[k], 0, 0, 0);
+            } else {
+                s[k] = zero16;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one tile of look-ahead, no further hoisting (it would spill)
+        }
+    } else {
+        // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int t = tile(k);
+            s[k] = zero16;
+            if (t >= 0) {
+                const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + g * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qcur[g][e], s[k], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- softmax numerators over these keys (registers x tiles in-lane, then the other lane-half).
+    // exp2((s - max s) * log2(e)/8): the 1/sqrt(64) scale rides in the exp2 argument; only the last key tile of
+    // the sequence can hold padded keys, so only it is masked.
+    mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int t = tile(k);
+        if (t >= 0) {
+            if (t == nkt - 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (key >= L) s[k][e] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[k][e]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
+    const float mxs = mx * kScaleLog2e;
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        if (tile(k) >= 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p;
+                // L = 256 + extras: the 9th key tile holds 1 or 2 real keys (registers 0, 1 of lane half 0); the other 14
+                // registers are padded keys in both halves -- a literal 0 instead of exp2(-inf): a tenth of the kernel's
+                // exponentials, which are what bounds it
+                if (NKT == 9 && NT == 9 && k == 8 && e >= 2) {
+                    s[k][e] = 0.f;
+                    continue;
+                }
+                if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[k][e], kScaleLog2e, -mxs));
+                else p = expf((s[k][e] - mx) * 0.125f);
+                s[k][e] = p;
+                sum += p;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+
+    // ---- O^T = V^T . P^T : two 32(d) x 32(q) tiles
+    o[0] = zero16;
+    o[1] = zero16;
+
+    if constexpr (sizeof(T) == 2) {
+        // V^T fragments double-buffered like the K fragments: [st][dt], keys t*32 + 16*st + 4*half + {0..3, 8..11}
+        typedef __attribute__((ext_vector_type(4))) short s4;
+        struct VF { s4 lo[2][2], hi[2][2]; };
+        // lane = (half, dhalf, q, p): its 16-lane group reads the block keys 16 st + 4 half + {0..3} (hi: + 8) x d 16 dhalf .. + 15
+        // of d-tile dt and supplies the address of row q, 8-byte piece p; lane i of the group receives column i, i.e. this
+        // lane ends up with V[those 4 keys][dt * 32 + (lane & 31)] -- the V^T fragment the MFMA wants.
+        const int tq = (lane >> 2) & 3, tp = lane & 3, dhalf = (lane >> 4) & 1;
+        const char* vb0 = Vt + (4 * half + tq) * Lay::kRowV + 8 * (tp & 1);
+        const char* vbd[2] = {vb0 + (((2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4), vb0 + (((4 + 2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4)};
+        typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
+        auto load_v = [&](int t, VF& f) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vr = vbd[dt] + (t * 32 + 16 * st) * Lay::kRowV;
+                    f.lo[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr));
+                    f.hi[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr + 8 * Lay::kRowV));
+                }
+        };
+        VF va, vb;
+        if (tile(0) >= 0) load_v(tile(0), va);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int t = tile(k);
+            const int tn = k + 1 < NT ? tile(k + 1) : -1;
+            if (tn >= 0) { if (k & 1) load_v(tn, va); else load_v(tn, vb); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t >= 0) {
+                const VF& f = (k & 1) ? vb : va;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
+                    // t*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[k][8 * st + j]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        bf16x8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vf[j] = f.lo[st][dt][j]; vf[4 + j] = f.hi[st][dt][j]; }
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int t = tile(k);
+            if (t >= 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // registers 4g..4g+3 are keys t*32 + 8g + 4*half + (0..3): contiguous in V^T
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 8 * g + 4 * half) * 4;
+                        const f32x4 vf = *reinterpret_cast<const f32x4*>(vr);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[k][4 * g + e], o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // NKT > 0: the number of 32-key tiles is a compile-time constant (9 for L = 257/258: every shipped
 // config), which removes the per-tile uniform guards, confines the padded-key mask to the last tile's
 // 16 registers and takes ~1000 SGPR-spill lane moves out of the chunk body.  NKT == 0: generic L <= 288.
@@ -135,185 +322,6 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
     __syncthreads();
 
-    // One 32-query chunk against NT key tiles tile(0..NT-1) (a negative index = skip): unnormalised
-    // O^T (two 32(d) x 32(q) tiles), the chunk's running max and the sum of exponentials.
-    auto attend = [&](auto nt_tag, auto&& tile, const f32x4 (&qcur)[NQF], f32x16 (&o)[2], float& mx, float& sum) {
-        constexpr int NT = decltype(nt_tag)::value;
-        // ---- S^T = K . Q^T, tiles of 32 keys x 32 queries
-        // (accumulators start from a literal zero C operand in the first MFMA of a tile: a separate zero-fill is 16 v_mov per
-        // tile -- 176 issue slots per chunk in a kernel that is bound by vector issue, not by the matrix pipe)
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 s[NT];
-
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 qf[4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qcur[st]);
-            // K fragments double-buffered: tile k+1's four ds_read_b128 are issued before tile k's MFMAs, so the LDS latency
-            // hides under them (the plain read -> wait -> MFMA chain spent most of a chunk in s_waitcnt lgkmcnt)
-            auto load_k = [&](int t, bf16x8 (&kf)[4]) {
-                const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
-                const int sw = (r32 >> 1) & 7;                         // (32 t contributes 0 to (row >> 1) & 7)
-#pragma unroll
-                for (int st = 0; st < 4; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kr + (((2 * st + half) ^ sw) << 4));
-            };
-            bf16x8 kfa[4], kfb[4];
-            if (tile(0) >= 0) load_k(tile(0), kfa);
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int t = tile(k);
-                const int tn = k + 1 < NT ? tile(k + 1) : -1;
-                if (tn >= 0) { if (k & 1) load_k(tn, kfa); else load_k(tn, kfb); }
-                __builtin_amdgcn_sched_barrier(0);  // the look-ahead reads go out BEFORE this tile's MFMAs
-                if (t >= 0) {
-                    s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[0] : kfa[0], qf[0], zero16, 0, 0, 0);
-#pragma unroll
-                    for (int st = 1; st < 4; ++st)
-                        s[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((k & 1) ? kfb[st] : kfa[st], qf[st], s[k], 0, 0, 0);
-                } else {
-                    s[k] = zero16;
-                }
-                __builtin_amdgcn_sched_barrier(0);  // one tile of look-ahead, no further hoisting (it would spill)
-            }
-        } else {
-            // fp32: lane-half `half` owns d in [32*half, 32*half+32); MFMA m consumes d = 32*half + m
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int t = tile(k);
-                s[k] = zero16;
-                if (t >= 0) {
-                    const char* kr = Ks + (t * 32 + r32) * Lay::kRowK + (32 * half) * 4;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + g * 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            s[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qcur[g][e], s[k], 0, 0, 0);
-                    }
-                }
-            }
-        }
-
-        // ---- softmax numerators over these keys (registers x tiles in-lane, then the other lane-half).
-        // exp2((s - max s) * log2(e)/8): the 1/sqrt(64) scale rides in the exp2 argument; only the last key tile of
-        // the sequence can hold padded keys, so only it is masked.
-        mx = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int t = tile(k);
-            if (t >= 0) {
-                if (t == nkt - 1) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                        if (key >= L) s[k][e] = -INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[k][e]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;
-        const float mxs = mx * kScaleLog2e;
-        sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            if (tile(k) >= 0) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float p;
-                    // L = 256 + extras: the 9th key tile holds 1 or 2 real keys (registers 0, 1 of lane half 0); the other 14
-                    // registers are padded keys in both halves -- a literal 0 instead of exp2(-inf): a tenth of the kernel's
-                    // exponentials, which are what bounds it
-                    if (NKT == 9 && NT == 9 && k == 8 && e >= 2) {
-                        s[k][e] = 0.f;
-                        continue;
-                    }
-                    if constexpr (sizeof(T) == 2) p = __builtin_amdgcn_exp2f(fmaf(s[k][e], kScaleLog2e, -mxs));
-                    else p = expf((s[k][e] - mx) * 0.125f);
-                    s[k][e] = p;
-                    sum += p;
-                }
-            }
-        }
-        sum += __shfl_xor(sum, 32);
-
-        // ---- O^T = V^T . P^T : two 32(d) x 32(q) tiles
-        o[0] = zero16;
-        o[1] = zero16;
-
-        if constexpr (sizeof(T) == 2) {
-            // V^T fragments double-buffered like the K fragments: [st][dt], keys t*32 + 16*st + 4*half + {0..3, 8..11}
-            typedef __attribute__((ext_vector_type(4))) short s4;
-            struct VF { s4 lo[2][2], hi[2][2]; };
-            // lane = (half, dhalf, q, p): its 16-lane group reads the block keys 16 st + 4 half + {0..3} (hi: + 8) x d 16 dhalf .. + 15
-            // of d-tile dt and supplies the address of row q, 8-byte piece p; lane i of the group receives column i, i.e. this
-            // lane ends up with V[those 4 keys][dt * 32 + (lane & 31)] -- the V^T fragment the MFMA wants.
-            const int tq = (lane >> 2) & 3, tp = lane & 3, dhalf = (lane >> 4) & 1;
-            const char* vb0 = Vt + (4 * half + tq) * Lay::kRowV + 8 * (tp & 1);
-            const char* vbd[2] = {vb0 + (((2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4), vb0 + (((4 + 2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4)};
-            typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
-            auto load_v = [&](int t, VF& f) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const char* vr = vbd[dt] + (t * 32 + 16 * st) * Lay::kRowV;
-                        f.lo[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr));
-                        f.hi[st][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(size_t)lds_addr_of(vr + 8 * Lay::kRowV));
-                    }
-            };
-            VF va, vb;
-            if (tile(0) >= 0) load_v(tile(0), va);
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int t = tile(k);
-                const int tn = k + 1 < NT ? tile(k + 1) : -1;
-                if (tn >= 0) { if (k & 1) load_v(tn, va); else load_v(tn, vb); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (t >= 0) {
-                    const VF& f = (k & 1) ? vb : va;
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        // B operand: accumulator registers 8*st .. 8*st+7 as bf16; element j is key
-                        // t*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
-                        bf16x8 pf;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[k][8 * st + j]);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            bf16x8 vf;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { vf[j] = f.lo[st][dt][j]; vf[4 + j] = f.hi[st][dt][j]; }
-                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int t = tile(k);
-                if (t >= 0) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        // registers 4g..4g+3 are keys t*32 + 8g + 4*half + (0..3): contiguous in V^T
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const char* vr = Vt + (dt * 32 + r32) * Lay::kRowV + (t * 32 + 8 * g + 4 * half) * 4;
-                            const f32x4 vf = *reinterpret_cast<const f32x4*>(vr);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[k][4 * g + e], o[dt], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
     // L = 32*8 + 1 or 2 (every shipped config): the 9th query chunk holds only the extra time / label tokens.  Given to
     // one wave it would cost a whole chunk (3 chunks on one wave against 2 on the others = +25 % on the workgroup); instead
     // all four waves take it together, each against its own key tiles, and the partial results are merged through LDS.
@@ -330,7 +338,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 
         f32x16 o[2];
         float mx, sum;
-        attend(std::integral_constant<int, kMaxKeyTiles>{}, [&](int k) { return k < nkt ? k : -1; }, qcur, o, mx, sum);
+        attend_tiles<T, NKT, kMaxKeyTiles, false>(Ks, Vt, L, nkt, lane, [&](int k) { return k < nkt ? k : -1; }, qcur, o, mx, sum);
         const float inv = 1.0f / sum;
 
         // ---- store: lane = query, registers = d ; 4 consecutive d per register quad
@@ -374,7 +382,7 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
         const int rem = L - 256;                                                               // 1 or 2 valid queries
         f32x16 o[2];
         float mx, sum;
-        attend(std::integral_constant<int, 3>{}, [&](int k) { return k < 2 ? wave + 4 * k : (wave == 3 ? 8 : -1); }, qnext, o, mx, sum);
+        attend_tiles<T, NKT, 3, false>(Ks, Vt, L, nkt, lane, [&](int k) { return k < 2 ? wave + 4 * k : (wave == 3 ? 8 : -1); }, qnext, o, mx, sum);
         if (r32 < rem) {
             float* pw = part + (wave * 2 + r32) * 66;
 #pragma unroll
@@ -405,6 +413,243 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn.qkv + attention in one launch (bf16, L = 256 patches + 1 or 2 extra tokens, head_dim 64).
+//
+// reference models/uvit.py:152-164: qkv = Linear(norm1(x)); q, k, v = split; softmax(q k^T / 8) v.  The plain path writes
+// the [B L, 3 D] qkv tensor (101 MB at B = 128) and reads it back one launch later; here a workgroup = one (image, head)
+// computes its own 256 x 192 slice of the Linear from the norm1 rows and keeps it on the CU:
+//   phase A  8 waves x 32 patch rows.  The wave's rows of h = norm1(x) sit in registers as MFMA B fragments (32 k-steps);
+//            the head's six 32-column weight tiles (q0 q1 k0 k1 v0 v1; host-packed in fragment order, qkv_attention_pack)
+//            stream through a 2 x 32 KB LDS ring by LDS-DMA, every wave multiplies each tile against its rows:
+//            out^T[col, row] so that a lane owns a row.  q stays in registers (already the B fragments of S^T = K Q^T, in
+//            accumulator k order), k and v are written to the LDS images the attention core reads (K rows in that same
+//            accumulator order, V row-major).
+//   extras   the 1 or 2 extra tokens' q / k / v rows come from the head-major qkv buffer (qkv_rows_kernel wrote them): their
+//            K / V rows go behind the patch rows in the images (softmax is order-free), their queries are the split last chunk.
+//   phase B  attend_tiles, one 32-query chunk per wave, then the split chunk of the extra tokens over all 8 waves.
+// Image rows: r in [0, 256) = token E + r, rows 256 .. 256 + E - 1 = tokens 0 .. E - 1, the rest zero (masked).
+struct QkvAttnArgs {
+    const bf16_t* h;       // norm1 of the patch rows in fragment order: [B * 8 groups of 32 rows][D / 16][64 lanes][8] (MlpFusedArgs::ln_out_frag)
+    const bf16_t* wimg;    // [H][6 tiles][D / 16 k-steps][64 lanes][8] (qkv_attention_pack)
+    const float* bias;     // [3 D] or nullptr
+    const bf16_t* qkv;     // head-major qkv tensor: only the extra-token rows are read
+    bf16_t* out;           // [B L, D]
+    int B, L, H, Lp, E;
+};
+
+constexpr int kQaPartBytes = 8 * 2 * 66 * 4;   // split chunk: [8 waves][2 queries][64 d, max, sum] fp32
+
+#ifdef DD_QA_TIMING   // development: phase timestamps (100 MHz) of every workgroup, left in the first output row of its (image, head)
+#define QA_STAMP(i) do { if (threadIdx.x == 0) qa_ts[i] = wall_clock64(); } while (0)
+#else
+#define QA_STAMP(i) do { } while (0)
+#endif
+
+template <int D>
+__global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs a) {
+    using Lay = AttnLayout<bf16_t>;
+#ifdef DD_QA_TIMING
+    unsigned long long qa_ts[16];
+    for (int i = 0; i < 16; ++i) qa_ts[i] = 0;
+#endif
+    QA_STAMP(0);
+    constexpr int KS = D / 16, BLK = KS * 1024, PPW = BLK / 1024 / 8;   // k-steps, bytes per weight tile, 1 KB DMA pieces per wave
+    static_assert(BLK % 8192 == 0, "a weight tile is DMA'd as 1 KB pieces spread evenly over 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + kLP * Lay::kRowK;
+    float* part = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + Lay::kVBytes);
+    char* ring = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaPartBytes;
+
+    // XCD-aware placement (workgroup i runs on XCD i % 8): the H heads of an image read the same 256 KB of h, so they take
+    // consecutive slots of ONE XCD and its L2 fetches those rows once
+    int b, hh;
+    if ((a.B & 7) == 0) { const int slot = blockIdx.x >> 3; b = (blockIdx.x & 7) + 8 * (slot / a.H); hh = slot % a.H; }
+    else { b = blockIdx.x / a.H; hh = blockIdx.x % a.H; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, r32 = lane & 31;
+    const int L = a.L, E = a.E, H = a.H;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- this wave's 32 rows of h as B fragments (k-step ks: k = 16 ks + 8 half .. + 7): the fused block tail left them in exactly
+    // this order ([32-row group][k-step][lane] x 16 bytes: MlpFusedArgs::ln_out_frag), one contiguous KB per load instruction
+    const int row = 32 * wave + r32;                                   // image row = patch index
+    const bf16x8* hfr = reinterpret_cast<const bf16x8*>(a.h) + ((long long)b * 8 + wave) * KS * 64 + lane;
+    bf16x8 xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = hfr[ks * 64];
+
+    const char* wsrc = reinterpret_cast<const char*>(a.wimg) + (size_t)hh * 6 * BLK + lane * 16;
+    auto dma_tile = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)j * BLK + p * 1024), (lptr_t)(ring + (j & 1) * BLK + p * 1024), 16, 0, 0);
+        }
+    };
+    dma_tile(0);
+    QA_STAMP(1);
+
+    // ---- the extra tokens' K / V rows (head-major buffer, standard d order) and the zero rows behind them
+    const long long unit = (long long)a.Lp * kHD;
+    const bf16_t* qx = a.qkv + ((long long)b * 3 * H + hh) * unit;
+    if (tid < E * 32) {
+        const int ei = tid >> 5, isv = (tid >> 4) & 1, grp = tid & 15, r = 256 + ei;      // 4 d = 8 bytes per thread
+        const uint2 val = *reinterpret_cast<const uint2*>(qx + (isv ? 2 : 1) * (long long)H * unit + (long long)ei * kHD + 4 * grp);
+        if (isv) {
+            *reinterpret_cast<uint2*>(Vt + r * 128 + (((grp >> 1) ^ (2 * (r & 3))) << 4) + 8 * (grp & 1)) = val;
+        } else {
+            // d0 = 4 grp = 32 T + 8 gq + 4 hf  ->  chunk 4 T + 2 hf + (gq >> 1), piece gq & 1 (accumulator order, see KPERM)
+            const int T = grp >> 3, gq = (grp >> 1) & 3, hf = grp & 1;
+            *reinterpret_cast<uint2*>(Ks + r * 128 + (((4 * T + 2 * hf + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + 8 * (gq & 1)) = val;
+        }
+    }
+    for (int i = tid; i < (kLP - 256 - E) * 16; i += 512) {
+        const int r = 256 + E + (i >> 4), c = i & 15;
+        *reinterpret_cast<f32x4*>((c < 8 ? Ks : Vt) + r * 128 + (c & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- phase A
+    f32x4 qcur[4];
+    const int swk = (row >> 1) & 7, swv = 2 * (row & 3);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile j have landed (hipcc does not track LDS-DMA writes)
+        __syncthreads();                                    // ... everyone's have, and nobody still reads the slot tile j + 1 goes to
+        QA_STAMP(2 + j);
+        if (j + 1 < 6) dma_tile(j + 1);
+        const char* wb = ring + (j & 1) * BLK + lane * 16;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // weight fragments four k-steps ahead of their MFMAs (the reads go out BEFORE the pair of MFMAs two steps older: hipcc
+        // otherwise issues read, read, wait, MFMA, MFMA and the LDS latency shows on every pair)
+        bf16x8 wq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+        f32x16 acc0 = zero16, acc1 = zero16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            const bf16x8 w0 = wq[ks & 3], w1 = wq[(ks + 1) & 3];
+            if (ks + 4 < KS) {
+                wq[ks & 3] = *reinterpret_cast<const bf16x8*>(wb + (ks + 4) * 1024);
+                wq[(ks + 1) & 3] = *reinterpret_cast<const bf16x8*>(wb + (ks + 5) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks + 1], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 acc = acc0 + acc1;
+        if (a.bias) {
+            const float* bj = a.bias + (j >> 1) * D + hh * kHD + 32 * (j & 1) + 4 * half;   // register e: column (e & 3) + 8 (e >> 2) + 4 half
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bj + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] += bv[e];
+            }
+        }
+        unsigned pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = (unsigned)f2bf(acc[2 * i]) | ((unsigned)f2bf(acc[2 * i + 1]) << 16);
+        const int T = j & 1;
+        if (j < 2) {            // q: registers 8 eh .. 8 eh + 7 of d tile T are k-step 2 T + eh of S^T = K Q^T
+            qcur[2 * T] = __builtin_bit_cast(f32x4, uint4{pk[0], pk[1], pk[2], pk[3]});
+            qcur[2 * T + 1] = __builtin_bit_cast(f32x4, uint4{pk[4], pk[5], pk[6], pk[7]});
+        } else if (j < 4) {     // k: the same order, chunk 4 T + 2 half + eh of the row
+            *reinterpret_cast<uint4*>(Ks + row * 128 + (((4 * T + 2 * half) ^ swk) << 4)) = uint4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<uint4*>(Ks + row * 128 + (((4 * T + 2 * half + 1) ^ swk) << 4)) = uint4{pk[4], pk[5], pk[6], pk[7]};
+        } else {                // v: row-major, register quad g = d 32 T + 8 g + 4 half .. + 3
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(Vt + row * 128 + (((4 * T + g) ^ swv) << 4) + 8 * half) = uint2{pk[2 * g], pk[2 * g + 1]};
+        }
+    }
+    __syncthreads();     // the K / V images are complete
+    QA_STAMP(8);
+
+    // the extra tokens' queries (the split chunk at the end) are fetched here: in flight under the main chunk
+    f32x4 qe[4];
+    {
+        const bf16_t* qrow = qx + (long long)(r32 < E ? r32 : E - 1) * kHD + 4 * half;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {     // k-step st = (T = st >> 1, eh = st & 1): d 32 T + 16 eh + 4 half + {0..3} and + 8
+            const uint2 lo = *reinterpret_cast<const uint2*>(qrow + 32 * (st >> 1) + 16 * (st & 1));
+            const uint2 hi = *reinterpret_cast<const uint2*>(qrow + 32 * (st >> 1) + 16 * (st & 1) + 8);
+            qe[st] = __builtin_bit_cast(f32x4, uint4{lo.x, lo.y, hi.x, hi.y});
+        }
+    }
+
+    // ---- phase B: this wave's 32 patch queries against all 9 key tiles
+    {
+        f32x16 o[2];
+        float mx, sum;
+        attend_tiles<bf16_t, 9, kMaxKeyTiles, true>(Ks, Vt, L, kMaxKeyTiles, lane, [&](int k) { return k; }, qcur, o, mx, sum);
+        const float inv = 1.0f / sum;
+        bf16_t* orow = a.out + ((long long)b * L + E + row) * D + hh * kHD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            uint2 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = f2bf(o[dt][4 * g + e] * inv);
+                v[g] = *reinterpret_cast<const uint2*>(v4);
+            }
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp].x, v[gp + 1].x, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp].y, v[gp + 1].y, false, false);
+                *reinterpret_cast<uint4*>(orow + dt * 32 + 8 * gp + 8 * half) = uint4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    }
+
+    QA_STAMP(9);
+    // ---- the extra tokens' queries: all 8 waves together, wave w against key tile w (wave 7: and the 9th), merged through LDS
+    {
+        f32x16 o[2];
+        float mx, sum;
+        attend_tiles<bf16_t, 9, 2, true>(Ks, Vt, L, kMaxKeyTiles, lane, [&](int k) { return k == 0 ? wave : (wave == 7 ? 8 : -1); }, qe, o, mx, sum);
+        if (r32 < E) {
+            float* pw = part + (wave * 2 + r32) * 66;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(pw + dt * 32 + 8 * g + 4 * half) =
+                        f32x4{o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]};
+            if (half == 0) { pw[64] = mx; pw[65] = sum; }
+        }
+        __syncthreads();
+        if (tid < E * 64) {
+            const int qi = tid >> 6, d = tid & 63;
+            float m[8], M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { m[w] = part[(w * 2 + qi) * 66 + 64]; M = fmaxf(M, m[w]); }
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float f = __builtin_amdgcn_exp2f((m[w] - M) * (0.125f * 1.4426950408889634f));
+                num = fmaf(f, part[(w * 2 + qi) * 66 + d], num);
+                den = fmaf(f, part[(w * 2 + qi) * 66 + 65], den);
+            }
+            a.out[((long long)b * L + qi) * D + hh * kHD + d] = f2bf(num / den);
+        }
+    }
+#ifdef DD_QA_TIMING
+    __syncthreads();
+    QA_STAMP(10);
+    if (threadIdx.x == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out + ((long long)b * L + E) * D + hh * kHD);
+        for (int i = 0; i < 16; ++i) dst[i] = qa_ts[i];
+    }
+#endif
+}
+
 }  // namespace
 
 template <typename T>
@@ -419,7 +664,36 @@ hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hi
     return hipGetLastError();
 }
 
+// attn.qkv weight [3 D, D] (nn.Linear layout) -> per head the six 32-column tiles q0 q1 k0 k1 v0 v1 in MFMA A-fragment order:
+// img[((head * 6 + j) * D / 16 + ks) * 512 + lane * 8 + i] = W[(j >> 1) D + 64 head + 32 (j & 1) + (lane & 31)][16 ks + 8 (lane >> 5) + i]
+void qkv_attention_pack(int D, int H, const float* w, unsigned short (*to_bf16)(float), unsigned short* img) {
+    const int KS = D / 16;
+    for (int hh = 0; hh < H; ++hh)
+        for (int j = 0; j < 6; ++j)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const float* src = w + ((size_t)(j >> 1) * D + 64 * hh + 32 * (j & 1) + (lane & 31)) * D + 16 * ks + 8 * (lane >> 5);
+                    unsigned short* dst = img + (((size_t)hh * 6 + j) * KS + ks) * 512 + lane * 8;
+                    for (int i = 0; i < 8; ++i) dst[i] = to_bf16(src[i]);
+                }
+}
+
+bool qkv_attention_supported(int D, int H, int L, int extras) {
+    return D == 512 && H * kHD == D && (extras == 1 || extras == 2) && L == 256 + extras;
+}
+
+static size_t qkv_attention_lds(int D) { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaPartBytes + (size_t)2 * (D / 16) * 1024; }
+
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* qkv, bf16_t* out,
+                                int B, int L, int H, int D, int extras, hipStream_t s) {
+    if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || !qkv || !out || B < 1) return hipErrorInvalidValue;
+    const QkvAttnArgs a{h, wimg, bias, qkv, out, B, L, H, make_head_major(L, H).Lp, extras};
+    hipLaunchKernelGGL((qkv_attention_kernel<512>), dim3(B * H), dim3(512), qkv_attention_lds(512), s, a);
+    return hipGetLastError();
+}
+
 hipError_t init_attention_kernels() {
+    if (hipError_t e = hipFuncSetAttribute((const void*)qkv_attention_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qkv_attention_lds(512)); e != hipSuccess) return e;
     const int lb = kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kPartBytes;
     const int lf = kLP * AttnLayout<float>::kRowK + AttnLayout<float>::kVBytes + kPartBytes;
     hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);

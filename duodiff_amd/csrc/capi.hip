@@ -63,6 +63,7 @@ struct BlockW {
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w, *skip_w;
     const char* mlp_img;     // fused-MLP weight image (mlp_fused.hip) or null
     const float* mlp_b1p;    // fc1 bias in accumulator-register order
+    const bf16_t* qa_img;    // attn.qkv weight per head in fragment order (qkv_attention_pack) or null
 };
 
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
@@ -108,7 +109,10 @@ struct dd_model {
     bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
                                           //     whose heads read every block's output)
     bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
+    bool fused_qa = false;                // attn.qkv computed inside the attention launch (attention.hip qkv_attention_kernel): takes precedence over
+                                          // fused_qkv wherever the previous block's fused launch leaves norm1 in h
     bf16_t* qkv_dump = nullptr;           // scratch for the qkv stores of rows past the end of a ragged tile
+    bf16_t* hfrag = nullptr;              // fused_qa: norm1 of the patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
@@ -397,6 +401,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     bool h_ready = false;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one)
     bool skip_done = false; // ... and x already holds that block's skip_linear output (the previous fused launch ran it too)
     bool qkv_done = false;  // ... and qkv already holds that block's attn.qkv output (ditto)
+    bool qa_ready = false;  // ... or only the extra-token rows of it: the patch rows' qkv is computed inside the attention launch
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
@@ -431,13 +436,18 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         skip_done = false;
         if (!h_ready && !qkv_done) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
         h_ready = false;
-        if (!qkv_done) {
-            GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
-            g.hm = make_head_major(L, m->H);     // head-major: each (q | k | v, head) unit of an image is contiguous (attention.hip)
-            DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
+        if (qa_ready) {
+            if constexpr (sizeof(T) == 2)
+                DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, (const bf16_t*)qkv, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
+        } else {
+            if (!qkv_done) {
+                GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
+                g.hm = make_head_major(L, m->H);     // head-major: each (q | k | v, head) unit of an image is contiguous (attention.hip)
+                DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
+            }
+            DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
         }
-        qkv_done = false;
-        DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
+        qkv_done = false; qa_ready = false;
         if (!(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
@@ -477,7 +487,12 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     h_ready = true; skip_done = true;
                 }
                 // the next block's attn.qkv last of all (where that block's skip_linear, if it has one, runs in here as well)
-                const bool qkv_next = m->fused_qkv && bi + 1 < nb && (bi < m->half_depth || skip_next);
+                // the next block's attn.qkv: inside its attention launch (fused_qa; only the extra-token rows' qkv is made here, by the
+                // small launch below), else last of all in this launch (fused_qkv) -- wherever this launch leaves that block's norm1
+                const bool h_next = bi + 1 < nb && (bi < m->half_depth || skip_next);
+                const bool qa_next = m->fused_qa && h_next;
+                const bool qkv_next = !qa_next && m->fused_qkv && h_next;
+                if (qa_next) fa.ln_out_frag = m->hfrag;      // the patch rows' norm1 in the order the attention launch loads it
                 if (qkv_next) {
                     const BlockW& wn = m->blocks[bi + 1];
                     fa.ln_out_g = wn.ln1_g; fa.ln_out_b = wn.ln1_b; fa.ln_out = (bf16_t*)h;   // (written for the extra-token rows only)
@@ -498,6 +513,12 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     DD_HIP(c, launch_mlp_reduce(fa, D, s));
                 }
                 if (qkv_next) DD_HIP(c, launch_qkv_rows(fa, D, s));   // the extra-token rows' qkv, from the norm1 rows the launch above wrote
+                if (qa_next) {
+                    MlpFusedArgs fq = fa;
+                    fq.qkv_out = (bf16_t*)qkv; fq.hm = make_head_major(L, m->H); fq.nqkv = 3 * D / 32;
+                    DD_HIP(c, launch_qkv_rows(fq, D, s));
+                    qa_ready = true;
+                }
                 continue;
             }
         }
@@ -787,8 +808,11 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
     m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
     m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
+    // (no qkv bias: the extra-token rows' qkv comes from qkv_rows_kernel, which has none)
+    m->fused_qa = m->fused_proj && m->ee_type < 0 && !m->cfg.qkv_bias && qkv_attention_supported(D, m->H, L, m->extras) &&
+                  !(c->dev_flags & DD_DEV_NO_FUSED_QA);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
-    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b; bool skip; };
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img; bool skip; };
     std::vector<BlockOff> boffs;
     // next_skip: prefix of the block whose skip_linear runs in THIS block's fused launch ("" = none)
     // next_qkv: prefix of the block whose attn.qkv runs in THIS block's fused launch ("" = none: the last block)
@@ -805,7 +829,8 @@ int dd_model_finalize(dd_model* m, int precision) {
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
         if (m->fused_mlp) {
             const bool with_skip = m->fused_skip && !next_skip.empty();
-            const bool with_qkv = m->fused_qkv && !next_qkv.empty() && (next_skip.empty() || with_skip);   // (an out-block's qkv needs its skip_linear in here too)
+            // (an out-block's qkv needs its skip_linear in here too; fused_qa: the section feeds qkv_rows_kernel -- the extra-token rows -- only)
+            const bool with_qkv = (m->fused_qkv || m->fused_qa) && !next_qkv.empty() && (next_skip.empty() || with_skip);
             o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj, with_skip, with_qkv));
             o.mlp_b1p = put_raw((size_t)hid * 4);
             const size_t proj_bytes = m->fused_proj ? (size_t)D * D * 2 : 0;      // D/32 blocks of Wproj lead the stream
@@ -818,6 +843,10 @@ int dd_model_finalize(dd_model* m, int precision) {
             if (with_qkv)     // the next block's attn.qkv: 3 D/32 blocks closing the image
                 mlp_fused_pack_rows(D, 3 * D, P(next_qkv + "attn.qkv.weight").data(), host_f2bf,
                                     (unsigned short*)&host[o.mlp_img + proj_bytes + ((size_t)(hid / 32) * 2 + (with_skip ? D / 16 : 0)) * (D / 16) * 1024]);
+        }
+        if (m->fused_qa) {
+            o.qa_img = put_raw((size_t)3 * D * D * 2);
+            qkv_attention_pack(D, m->H, P(p + "attn.qkv.weight").data(), host_f2bf, (unsigned short*)&host[o.qa_img]);
         }
         boffs.push_back(o);
     };
@@ -930,7 +959,7 @@ int dd_model_finalize(dd_model* m, int precision) {
         BlockW w{F(o.ln1_g), F(o.ln1_b), F(o.ln2_g), F(o.ln2_b), F(o.proj_b), F(o.fc1_b), F(o.fc2_b),
                  o.skip ? F(o.skip_b) : nullptr, m->cfg.qkv_bias ? F(o.qkv_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
                  o.skip ? V(o.skip_w) : nullptr, m->fused_mlp ? (const char*)V(o.mlp_img) : nullptr,
-                 m->fused_mlp ? F(o.mlp_b1p) : nullptr};
+                 m->fused_mlp ? F(o.mlp_b1p) : nullptr, m->fused_qa ? (const bf16_t*)V(o.qa_img) : nullptr};
         m->blocks.push_back(w);
     }
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
@@ -955,6 +984,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid) : 0;
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
+    const size_t o_hf = take(m->fused_qa ? (size_t)m->cfg.max_batch * m->N * D * 2 : 0);
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
     m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
@@ -963,6 +993,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->mlp_partial = part_bytes ? (float*)(m->wsarena + o_part) : nullptr;
     m->mlp_partial_bytes = part_bytes;
     m->qkv_dump = m->fused_qkv ? (bf16_t*)(m->wsarena + o_dump) : nullptr;
+    m->hfrag = m->fused_qa ? (bf16_t*)(m->wsarena + o_hf) : nullptr;
 
     // host copies are no longer needed
     for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
@@ -1442,6 +1473,60 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) { DD_TRY(launch_mlp_fused(a, D, s)); DD_TRY(launch_mlp_reduce(ar, D, s)); DD_TRY(launch_skip_rows_ln(a, D, s)); DD_TRY(launch_qkv_rows(a, D, s)); }
+        DD_TRY(hipEventRecord(e1, s));
+        DD_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DD_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_out = ms / (float)iters;
+    }
+#undef DD_TRY
+    cleanup();
+    return DD_OK;
+}
+
+int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float* h_host, const float* wqkv, const float* bqkv,
+                         unsigned short* out_host, int iters, void* stream, float* ms_out) {
+    if (!c || !h_host || !wqkv || !out_host) return DD_ERR_INVALID;
+    const int D = 64 * H;
+    if (!qkv_attention_supported(D, H, L, extras)) return fail(c, DD_ERR_UNSUPPORTED, "qkv_attention: D = 512, L = 256 + 1 or 2 extra tokens only");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)B * L;
+    const HeadMajor hm = make_head_major(L, H);
+    const size_t qkv_elems = (size_t)B * 3 * D * hm.Lp;
+    std::vector<unsigned short> hb(M * D), hf((size_t)B * 256 * D), img((size_t)3 * D * D), q(qkv_elems, 0);
+    for (size_t i = 0; i < hb.size(); ++i) hb[i] = host_f2bf(h_host[i]);
+    for (int b = 0; b < B; ++b)          // the patch rows in fragment order (what the fused block tail writes: MlpFusedArgs::ln_out_frag)
+        for (int n = 0; n < 256; ++n)
+            for (int k = 0; k < D; ++k)
+                hf[((((size_t)b * 8 + n / 32) * (D / 16) + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8] = hb[((size_t)b * L + extras + n) * D + k];
+    qkv_attention_pack(D, H, wqkv, host_f2bf, img.data());
+    auto bf = [](unsigned short v) { unsigned u = (unsigned)v << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    // the extra-token rows' qkv, as qkv_rows_kernel leaves it (bf16 operands, fp32 sum, bf16 result; head-major)
+    for (int b = 0; b < B; ++b)
+        for (int e = 0; e < extras; ++e)
+            for (int col = 0; col < 3 * D; ++col) {
+                double acc = bqkv ? bqkv[col] : 0.0;
+                for (int k = 0; k < D; ++k) acc += (double)bf(hb[((size_t)b * L + e) * D + k]) * (double)bf(host_f2bf(wqkv[(size_t)col * D + k]));
+                q[(((size_t)b * 3 * H + col / 64) * hm.Lp + e) * 64 + col % 64] = host_f2bf((float)acc);   // (dd_internal.h hm_offset)
+            }
+    void *dH = nullptr, *dW = nullptr, *dB = nullptr, *dQ = nullptr, *dO = nullptr;
+    auto cleanup = [&]() { for (void* p : {dH, dW, dB, dQ, dO}) if (p) (void)hipFree(p); };
+#define DD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(c, DD_ERR_HIP, hipGetErrorString(e_)); } } while (0)
+    DD_TRY(hipMalloc(&dH, hf.size() * 2)); DD_TRY(hipMalloc(&dW, img.size() * 2)); DD_TRY(hipMalloc(&dQ, q.size() * 2)); DD_TRY(hipMalloc(&dO, M * D * 2));
+    DD_TRY(hipMemcpy(dH, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dW, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dQ, q.data(), q.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemset(dO, 0, M * D * 2));
+    if (bqkv) { DD_TRY(hipMalloc(&dB, (size_t)3 * D * 4)); DD_TRY(hipMemcpy(dB, bqkv, (size_t)3 * D * 4, hipMemcpyHostToDevice)); }
+    DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, (bf16_t*)dO, B, L, H, D, extras, s));
+    DD_TRY(hipStreamSynchronize(s));
+    DD_TRY(hipMemcpy(out_host, dO, M * D * 2, hipMemcpyDeviceToHost));
+    if (iters > 0 && ms_out) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
+        DD_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, (bf16_t*)dO, B, L, H, D, extras, s));
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

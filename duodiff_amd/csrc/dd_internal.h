@@ -110,6 +110,8 @@ struct MlpFusedArgs {
     const float* bskip;    //            replaces y in xres, ln_out = norm1(x'); skip = the long-skip operand's rows [Mp, D]
     int nskip;             // 2 * D / 32 blocks of Wskip behind the MLP blocks of wimg (mlp_fused_pack_skip), or 0
     bf16_t* qkv_out;       // nqkv > 0: the NEXT block's attn.qkv (no bias) runs last (main tiles): qkv = norm1(updated rows) . Wqkv^T, written
+    bf16_t* ln_out_frag;   // or null: the main tiles write norm1 HERE instead of ln_out, in MFMA fragment order ([32-row group of patch rows]
+                           //          [D / 16 k-steps][64 lanes] x 16 bytes) for launch_qkv_attention; needs tok_n % 32 == 0
     bf16_t* qkv_dump;      //           head-major (hm) -- norm1 is then NOT written for the main rows; qkv_dump: 16 KB scratch (qkv | x | bf16 copy of rows past the end)
     HeadMajor hm;          //           (stores of rows past the end of a ragged tile)
     int nqkv;              // 3 * D / 32 blocks of Wqkv closing the image (mlp_fused_pack_rows), or 0
@@ -179,6 +181,13 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 // qkv: head-major (HeadMajor, make_head_major(L, H)); out: [B * L, D] rows
 template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
+// attn.qkv + attention in one launch (attention.hip qkv_attention_kernel): h = norm1 of the patch rows in fragment order
+// (MlpFusedArgs::ln_out_frag); wimg from qkv_attention_pack;
+// qkv = the head-major tensor holding the extra-token rows' q / k / v (launch_qkv_rows); bf16, D = 512, L = 256 + extras only
+bool qkv_attention_supported(int D, int H, int L, int extras);
+void qkv_attention_pack(int D, int H, const float* w, unsigned short (*to_bf16)(float), unsigned short* img);
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* qkv, bf16_t* out,
+                                int B, int L, int H, int D, int extras, hipStream_t s);
 
 struct FinalArgs {
     const float* dec;      // [B*L, pd] decoder_pred output for every token (extras included)

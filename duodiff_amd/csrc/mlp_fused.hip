@@ -834,6 +834,16 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             const float shift = -mean * rstd;
             const float* lb2r = lb2;
             asm volatile("" : "+v"(lb2r));        // a second read of the bias quads from LDS, not 64 values carried over from pass 1 (spills)
+            // where the 16-byte piece of k-step ks = 2t + gp2/2 goes: row-major rows, or (ln_out_frag) the MFMA fragment order the
+            // attention launch loads straight into registers -- [32-row group][k-step][lane] x 16 bytes, a wave's store = 1 KB contiguous
+            bf16_t* lnp = nullptr;
+            long long lnstride = 16;
+            if constexpr (!QKV && !PARTIAL) {
+                unsigned l = (unsigned)threadIdx.x;
+                asm volatile("" : "+v"(l));
+                if (a.ln_out_frag) { lnp = a.ln_out_frag + (((long long)tile_idx * 4 + (l >> 6)) * C::F * 64 + (l & 63)) * 8; lnstride = 512; }
+                else lnp = a.ln_out + row * D + 8 * he;
+            }
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 uint2 v[4];
@@ -860,7 +870,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                         const auto s0 = __builtin_amdgcn_permlane32_swap(v[gp2].x, v[gp2 + 1].x, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(v[gp2].y, v[gp2 + 1].y, false, false);
                         const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        *reinterpret_cast<uint4*>(a.ln_out + row * D + 32 * t + 8 * gp2 + 8 * he) = o;
+                        *reinterpret_cast<uint4*>(lnp + (2 * t + gp2 / 2) * lnstride) = o;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1265,6 +1275,7 @@ hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     const int grid = a.tiles_main + a.tiles_left * a.groups;
     if (a.nskip > 0 && (a.nproj <= 0 || a.nskip != D / 16 || !a.skip || !a.bskip || (!a.ln_out && a.nqkv <= 0) || a.nchunks % 2)) return hipErrorInvalidValue;
     if (a.nqkv > 0 && a.nproj <= 0) return hipErrorInvalidValue;
+    if (a.ln_out_frag && (!a.ln_out || a.nqkv > 0 || a.tok_n % 32)) return hipErrorInvalidValue;   // (whole 32-row groups of patch rows per wave)
     if (a.nproj > 0) {
         if constexpr (D % 128 == 0) {
             if (!a.ln_in_g || !a.ao || !a.bproj || a.nproj != D / 32) return hipErrorInvalidValue;

@@ -32,6 +32,14 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
                const float* ao_host, const float* wproj, const float* bproj, const float* skip_host, const float* wskip,
                const float* bskip, const float* wqkv, unsigned short* qkv_out_host);
 
+/* Development harness for the attention launch that computes attn.qkv itself (attention.hip qkv_attention_kernel; bf16, 8 heads
+ * of 64, L = 256 patches + `extras` = 1 or 2 leading extra tokens): out = softmax(q k^T / 8) v per (image, head) with
+ * q, k, v = split(h . wqkv^T + bqkv), from host arrays h [B L, 512] (rounded to bf16), wqkv [1536, 512], bqkv [1536] or NULL;
+ * out_host bf16 [B L, 512].  The extra-token rows' qkv (the model makes it with a small launch of its own) is computed on the
+ * host here.  `iters` timed launches -> ms_out. */
+int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const float* h_host, const float* wqkv, const float* bqkv,
+                         unsigned short* out_host, int iters, void* stream, float* ms_out);
+
 /* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
  * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
  * reads no environment variable. */
@@ -40,6 +48,7 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
 #define DD_DEV_NO_FUSED_HEAD 4u     /* keep final LayerNorm + decoder_pred as two launches */
 #define DD_DEV_NO_FUSED_SKIP 32u    /* keep skip_linear as its own GEMM + LayerNorm launch */
 #define DD_DEV_NO_FUSED_QKV 64u     /* keep attn.qkv as its own GEMM launch */
+#define DD_DEV_NO_FUSED_QA 128u     /* keep attn.qkv out of the attention launch (the qkv tensor goes through HBM) */
 #define DD_DEV_GENERIC_EMBED 8u     /* generic VALU patch-embed kernel */
 #define DD_DEV_MLP_EXTRAS_ONLY 16u  /* dd_dev_mlp: launch the hidden-split (extra-token) workgroups alone */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
