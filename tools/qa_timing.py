@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase timeline of qkv_attention_kernel from a -DDD_QA_TIMING variant build (tools/build_variant.py qat -DDD_QA_TIMING):
+"""Phase timeline of qkv_attention_kernel from an instrumented variant build.  The product source holds no instrumentation:
+    git apply tools/experiments/qkv_attention_timing.patch && python tools/build_variant.py qat -DDD_QA_TIMING && git apply -R tools/experiments/qkv_attention_timing.patch
     DUODIFF_LIB=duodiff_amd/libduodiff_qat.so python tools/qa_timing.py [B]
 Every workgroup leaves its 100 MHz timestamps in the first output row of its (image, head); prints the mean phase durations."""
 import ctypes as C
@@ -35,6 +36,12 @@ def main():
     d = np.diff(ts, axis=1) * 10.0 / 1e3                                     # us
     for i, n in enumerate(names):
         print(f"  {n:44s} mean {d[:, i].mean():7.2f} us  (min {d[:, i].min():6.2f}, max {d[:, i].max():6.2f})")
+    full = np.ascontiguousarray(rows).view(np.uint64).reshape(B * H, 16).astype(np.int64)
+    if full[:, 13].min() > 0:     # tile 2 in detail: barrier exit (stamp 4) -> DMA issued (11) -> MFMAs done (12) -> epilogue done (13) -> next barrier exit (5)
+        seq = np.stack([full[:, 4], full[:, 11], full[:, 12], full[:, 13], full[:, 5]], 1)
+        dd = np.diff(seq, axis=1) * 10.0 / 1e3
+        for i, n in enumerate(["tile2: DMA issue", "tile2: 32 MFMAs", "tile2: bias/pack/LDS writes", "tile2: wait + barrier of tile 3"]):
+            print(f"  {n:44s} mean {dd[:, i].mean():7.2f} us  (min {dd[:, i].min():6.2f}, max {dd[:, i].max():6.2f})")
     tot = (ts[:, 10] - ts[:, 0]) * 10.0 / 1e3
     print(f"  workgroup total mean {tot.mean():.2f} us; first start -> last end {(ts[:, 10].max() - t0) * 10.0 / 1e3:.2f} us; "
           f"start spread {(ts[:, 0].max() - t0) * 10.0 / 1e3:.2f} us")
