@@ -29,6 +29,13 @@ constexpr int kLP = kMaxKeyTiles * 32;   // padded key count held in LDS
 constexpr int kHD = 64;
 constexpr int kPartBytes = 4 * 2 * 66 * 4;   // split last query chunk: [4 waves][2 queries][64 d, max, sum] fp32
 
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (round to nearest even, as f2bf)
+    typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+    typedef float f32v2 __attribute__((ext_vector_type(2)));
+    const f32v2 q = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16v2));
+}
+
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -540,7 +547,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
         }
         unsigned pk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = (unsigned)f2bf(acc[2 * i]) | ((unsigned)f2bf(acc[2 * i + 1]) << 16);
+        for (int i = 0; i < 8; ++i) pk[i] = pack2_bf16(acc[2 * i], acc[2 * i + 1]);
         const int T = j & 1;
         if (j < 2) {            // q: registers 8 eh .. 8 eh + 7 of d tile T are k-step 2 T + eh of S^T = K Q^T
             qcur[2 * T] = __builtin_bit_cast(f32x4, uint4{pk[0], pk[1], pk[2], pk[3]});

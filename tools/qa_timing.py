@@ -37,10 +37,10 @@ def main():
     for i, n in enumerate(names):
         print(f"  {n:44s} mean {d[:, i].mean():7.2f} us  (min {d[:, i].min():6.2f}, max {d[:, i].max():6.2f})")
     full = np.ascontiguousarray(rows).view(np.uint64).reshape(B * H, 16).astype(np.int64)
-    if full[:, 13].min() > 0:     # tile 2 in detail: barrier exit (stamp 4) -> DMA issued (11) -> MFMAs done (12) -> epilogue done (13) -> next barrier exit (5)
-        seq = np.stack([full[:, 4], full[:, 11], full[:, 12], full[:, 13], full[:, 5]], 1)
+    if full[:, 12].min() > 0:     # tile 2 in detail: barrier exit (stamp 4) -> DMA issued (11) -> MFMAs done (12) -> epilogue done (13) -> next barrier exit (5)
+        seq = np.stack([full[:, 4], full[:, 11], full[:, 12], full[:, 5], full[:, 5]], 1)
         dd = np.diff(seq, axis=1) * 10.0 / 1e3
-        for i, n in enumerate(["tile2: DMA issue", "tile2: 32 MFMAs", "tile2: bias/pack/LDS writes", "tile2: wait + barrier of tile 3"]):
+        for i, n in enumerate(["tile2: whole tile until its wait", "tile3 head: vmcnt(0) wait (DMA of tile 3 landed)", "tile3 head: barrier", "-"]):
             print(f"  {n:44s} mean {dd[:, i].mean():7.2f} us  (min {dd[:, i].min():6.2f}, max {dd[:, i].max():6.2f})")
     tot = (ts[:, 10] - ts[:, 0]) * 10.0 / 1e3
     print(f"  workgroup total mean {tot.mean():.2f} us; first start -> last end {(ts[:, 10].max() - t0) * 10.0 / 1e3:.2f} us; "
