@@ -433,20 +433,26 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
 //            out^T[col, row] so that a lane owns a row.  q stays in registers (already the B fragments of S^T = K Q^T, in
 //            accumulator k order), k and v are written to the LDS images the attention core reads (K rows in that same
 //            accumulator order, V row-major).
-//   extras   the 1 or 2 extra tokens' q / k / v rows come from the head-major qkv buffer (qkv_rows_kernel wrote them): their
-//            K / V rows go behind the patch rows in the images (softmax is order-free), their queries are the split last chunk.
+//   extras   the 1 or 2 extra tokens' rows of h (row-major, written by the small reduce / skip_rows launches) are parked in LDS; their
+//            q / k / v are computed here too, as a ninth 32-row group whose k range is split over the 8 waves (4 extra MFMAs per
+//            tile and wave; partial sums through LDS): their K / V rows go behind the patch rows in the images (softmax is
+//            order-free), their queries are the split last chunk.
 //   phase B  attend_tiles, one 32-query chunk per wave, then the split chunk of the extra tokens over all 8 waves.
 // Image rows: r in [0, 256) = token E + r, rows 256 .. 256 + E - 1 = tokens 0 .. E - 1, the rest zero (masked).
 struct QkvAttnArgs {
     const bf16_t* h;       // norm1 of the patch rows in fragment order: [B * 8 groups of 32 rows][D / 16][64 lanes][8] (MlpFusedArgs::ln_out_frag)
     const bf16_t* wimg;    // [H][6 tiles][D / 16 k-steps][64 lanes][8] (qkv_attention_pack)
     const float* bias;     // [3 D] or nullptr
-    const bf16_t* qkv;     // head-major qkv tensor: only the extra-token rows are read
+    const bf16_t* hx;      // norm1 rows, row-major [B L, D]: only the extra-token rows (l < E) are read
     bf16_t* out;           // [B L, D]
     int B, L, H, Lp, E;
 };
 
-constexpr int kQaPartBytes = 8 * 2 * 66 * 4;   // split chunk: [8 waves][2 queries][64 d, max, sum] fp32
+// LDS behind the K / V images: px = the extra rows' partial q / k / v sums [8 waves][6 tiles][2 rows][32 columns] fp32 (the split
+// chunk's [8 waves][2 queries][64 d, max, sum] fp32 reuses its start later) | hxl = the extra rows of h [2][D] bf16 | qxl = their q [2][64] bf16
+constexpr int kQaPxBytes = 8 * 6 * 2 * 32 * 4;
+constexpr int kQaAuxBytes = kQaPxBytes + 2 * 1024 + 256;
+static_assert(8 * 2 * 66 * 4 <= kQaPxBytes, "the split chunk's partials reuse the px area");
 
 template <int D>
 __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs a) {
@@ -456,8 +462,12 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vt = smem + kLP * Lay::kRowK;
-    float* part = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + Lay::kVBytes);
-    char* ring = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaPartBytes;
+    static_assert(D * 2 == 1024, "hxl holds two rows of D bf16 in 2 KB");
+    float* px = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + Lay::kVBytes);
+    float* part = px;
+    char* hxl = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaPxBytes;
+    char* qxl = hxl + 2 * 1024;
+    char* ring = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaAuxBytes;
 
     // XCD-aware placement (workgroup i runs on XCD i % 8): the H heads of an image read the same 256 KB of h, so they take
     // consecutive slots of ONE XCD and its L2 fetches those rows once
@@ -488,20 +498,8 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     };
     dma_tile(0);
 
-    // ---- the extra tokens' K / V rows (head-major buffer, standard d order) and the zero rows behind them
-    const long long unit = (long long)a.Lp * kHD;
-    const bf16_t* qx = a.qkv + ((long long)b * 3 * H + hh) * unit;
-    if (tid < E * 32) {
-        const int ei = tid >> 5, isv = (tid >> 4) & 1, grp = tid & 15, r = 256 + ei;      // 4 d = 8 bytes per thread
-        const uint2 val = *reinterpret_cast<const uint2*>(qx + (isv ? 2 : 1) * (long long)H * unit + (long long)ei * kHD + 4 * grp);
-        if (isv) {
-            *reinterpret_cast<uint2*>(Vt + r * 128 + (((grp >> 1) ^ (2 * (r & 3))) << 4) + 8 * (grp & 1)) = val;
-        } else {
-            // d0 = 4 grp = 32 T + 8 gq + 4 hf  ->  chunk 4 T + 2 hf + (gq >> 1), piece gq & 1 (accumulator order, see KPERM)
-            const int T = grp >> 3, gq = (grp >> 1) & 3, hf = grp & 1;
-            *reinterpret_cast<uint2*>(Ks + r * 128 + (((4 * T + 2 * hf + (gq >> 1)) ^ ((r >> 1) & 7)) << 4) + 8 * (gq & 1)) = val;
-        }
-    }
+    // ---- the extra tokens' rows of h into LDS (every wave reads its k range of them in every tile); zero rows behind the images' last
+    if (tid < E * 64) *reinterpret_cast<f32x4*>(hxl + tid * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + (tid >> 6)) * D + (tid & 63) * 8);
     for (int i = tid; i < (kLP - 256 - E) * 16; i += 512) {
         const int r = 256 + E + (i >> 4), c = i & 15;
         *reinterpret_cast<f32x4*>((c < 8 ? Ks : Vt) + r * 128 + (c & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -536,6 +534,21 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 acc = acc0 + acc1;
+        {   // the extra tokens' rows against this tile: k-steps [wave KS/8, (wave + 1) KS/8) only -- the 8 waves' partial sums meet in LDS
+            // (a ninth row group's worth of MFMAs spread evenly: + 1/8 on phase A; placing them between the main MFMAs measured the same)
+            f32x16 accx = zero16;
+            const char* hxb = hxl + (r32 < E ? r32 : 0) * (D * 2) + 16 * half;
+#pragma unroll
+            for (int i = 0; i < KS / 8; ++i) {
+                const int ks = wave * (KS / 8) + i;
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), *reinterpret_cast<const bf16x8*>(hxb + ks * 32), accx, 0, 0, 0);
+            }
+            if (r32 < E) {
+                float* pp = px + ((wave * 6 + j) * 2 + r32) * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(pp + 8 * g) = f32x4{accx[4 * g], accx[4 * g + 1], accx[4 * g + 2], accx[4 * g + 3]};
+            }
+        }
         if (a.bias) {
             const float* bj = a.bias + (j >> 1) * D + hh * kHD + 32 * (j & 1) + 4 * half;   // register e: column (e & 3) + 8 (e >> 2) + 4 half
 #pragma unroll
@@ -561,12 +574,29 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
                 *reinterpret_cast<uint2*>(Vt + row * 128 + (((4 * T + g) ^ swv) << 4) + 8 * half) = uint2{pk[2 * g], pk[2 * g + 1]};
         }
     }
+    __syncthreads();     // every wave's partial sums of the extra rows are in px
+    if (tid < E * 192) {
+        const int e = tid / 192, c = tid % 192, j = c >> 5, col = c & 31;
+        float v = a.bias ? a.bias[(j >> 1) * D + hh * kHD + 32 * (j & 1) + col] : 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += px[((w * 6 + j) * 2 + e) * 32 + col];
+        const bf16_t vb = f2bf(v);
+        const int d = 32 * (j & 1) + col, r = 256 + e;
+        if (j < 2) {
+            *reinterpret_cast<bf16_t*>(qxl + e * 128 + d * 2) = vb;
+        } else if (j < 4) {      // K row in accumulator order (KPERM): d = 32 T + (ae & 3) + 8 (ae >> 2) + 4 hf -> chunk 4 T + 2 hf + (ae >> 3), element ae & 7
+            const int T = d >> 5, dd = d & 31, hf = (dd >> 2) & 1, ae = (dd & 3) + 4 * (dd >> 3);
+            *reinterpret_cast<bf16_t*>(Ks + r * 128 + (((4 * T + 2 * hf + (ae >> 3)) ^ ((r >> 1) & 7)) << 4) + (ae & 7) * 2) = vb;
+        } else {
+            *reinterpret_cast<bf16_t*>(Vt + r * 128 + (((d >> 3) ^ (2 * (r & 3))) << 4) + (d & 7) * 2) = vb;
+        }
+    }
     __syncthreads();     // the K / V images are complete
 
-    // the extra tokens' queries (the split chunk at the end) are fetched here: in flight under the main chunk
+    // the extra tokens' queries (the split chunk at the end), in accumulator k order like the patch rows' own
     f32x4 qe[4];
     {
-        const bf16_t* qrow = qx + (long long)(r32 < E ? r32 : E - 1) * kHD + 4 * half;
+        const bf16_t* qrow = reinterpret_cast<const bf16_t*>(qxl) + (r32 < E ? r32 : E - 1) * kHD + 4 * half;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {     // k-step st = (T = st >> 1, eh = st & 1): d 32 T + 16 eh + 4 half + {0..3} and + 8
             const uint2 lo = *reinterpret_cast<const uint2*>(qrow + 32 * (st >> 1) + 16 * (st & 1));
@@ -666,12 +696,12 @@ bool qkv_attention_supported(int D, int H, int L, int extras) {
     return D == 512 && H * kHD == D && (extras == 1 || extras == 2) && L == 256 + extras;
 }
 
-static size_t qkv_attention_lds(int D) { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaPartBytes + (size_t)2 * (D / 16) * 1024; }
+static size_t qkv_attention_lds(int D) { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaAuxBytes + (size_t)2 * (D / 16) * 1024; }
 
-hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* qkv, bf16_t* out,
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, bf16_t* out,
                                 int B, int L, int H, int D, int extras, hipStream_t s) {
-    if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || !qkv || !out || B < 1) return hipErrorInvalidValue;
-    const QkvAttnArgs a{h, wimg, bias, qkv, out, B, L, H, make_head_major(L, H).Lp, extras};
+    if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || !hx || !out || B < 1) return hipErrorInvalidValue;
+    const QkvAttnArgs a{h, wimg, bias, hx, out, B, L, H, make_head_major(L, H).Lp, extras};
     hipLaunchKernelGGL((qkv_attention_kernel<512>), dim3(B * H), dim3(512), qkv_attention_lds(512), s, a);
     return hipGetLastError();
 }

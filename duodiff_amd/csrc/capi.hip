@@ -438,7 +438,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         h_ready = false;
         if (qa_ready) {
             if constexpr (sizeof(T) == 2)
-                DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, (const bf16_t*)qkv, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
+                DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, (const bf16_t*)h, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
         } else {
             if (!qkv_done) {
                 GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
@@ -487,8 +487,8 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     h_ready = true; skip_done = true;
                 }
                 // the next block's attn.qkv last of all (where that block's skip_linear, if it has one, runs in here as well)
-                // the next block's attn.qkv: inside its attention launch (fused_qa; only the extra-token rows' qkv is made here, by the
-                // small launch below), else last of all in this launch (fused_qkv) -- wherever this launch leaves that block's norm1
+                // the next block's attn.qkv: inside its attention launch (fused_qa), else last of all in this launch (fused_qkv) --
+                // wherever this launch leaves that block's norm1
                 const bool h_next = bi + 1 < nb && (bi < m->half_depth || skip_next);
                 const bool qa_next = m->fused_qa && h_next;
                 const bool qkv_next = !qa_next && m->fused_qkv && h_next;
@@ -513,12 +513,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     DD_HIP(c, launch_mlp_reduce(fa, D, s));
                 }
                 if (qkv_next) DD_HIP(c, launch_qkv_rows(fa, D, s));   // the extra-token rows' qkv, from the norm1 rows the launch above wrote
-                if (qa_next) {
-                    MlpFusedArgs fq = fa;
-                    fq.qkv_out = (bf16_t*)qkv; fq.hm = make_head_major(L, m->H); fq.nqkv = 3 * D / 32;
-                    DD_HIP(c, launch_qkv_rows(fq, D, s));
-                    qa_ready = true;
-                }
+                qa_ready = qa_next;    // (the extra-token rows' norm1 is in h, row-major: the reduce / skip_rows launch above wrote it)
                 continue;
             }
         }
@@ -808,9 +803,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
     m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
     m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
-    // (no qkv bias: the extra-token rows' qkv comes from qkv_rows_kernel, which has none)
-    m->fused_qa = m->fused_proj && m->ee_type < 0 && !m->cfg.qkv_bias && qkv_attention_supported(D, m->H, L, m->extras) &&
-                  !(c->dev_flags & DD_DEV_NO_FUSED_QA);
+    m->fused_qa = m->fused_proj && m->ee_type < 0 && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img; bool skip; };
     std::vector<BlockOff> boffs;
@@ -829,8 +822,8 @@ int dd_model_finalize(dd_model* m, int precision) {
         if (skip) { o.skip_b = put_f32(P(p + "skip_linear.bias").data(), D); o.skip_w = put_mat(P(p + "skip_linear.weight")); }
         if (m->fused_mlp) {
             const bool with_skip = m->fused_skip && !next_skip.empty();
-            // (an out-block's qkv needs its skip_linear in here too; fused_qa: the section feeds qkv_rows_kernel -- the extra-token rows -- only)
-            const bool with_qkv = (m->fused_qkv || m->fused_qa) && !next_qkv.empty() && (next_skip.empty() || with_skip);
+            // (an out-block's qkv needs its skip_linear in here too; with fused_qa the attention launch computes qkv and no section is packed)
+            const bool with_qkv = m->fused_qkv && !m->fused_qa && !next_qkv.empty() && (next_skip.empty() || with_skip);
             o.mlp_img = put_raw(mlp_fused_image_bytes(D, hid, m->fused_proj, with_skip, with_qkv));
             o.mlp_b1p = put_raw((size_t)hid * 4);
             const size_t proj_bytes = m->fused_proj ? (size_t)D * D * 2 : 0;      // D/32 blocks of Wproj lead the stream
@@ -1492,31 +1485,20 @@ int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float
     if (!qkv_attention_supported(D, H, L, extras)) return fail(c, DD_ERR_UNSUPPORTED, "qkv_attention: D = 512, L = 256 + 1 or 2 extra tokens only");
     hipStream_t s = (hipStream_t)stream;
     const size_t M = (size_t)B * L;
-    const HeadMajor hm = make_head_major(L, H);
-    const size_t qkv_elems = (size_t)B * 3 * D * hm.Lp;
-    std::vector<unsigned short> hb(M * D), hf((size_t)B * 256 * D), img((size_t)3 * D * D), q(qkv_elems, 0);
+    std::vector<unsigned short> hb(M * D), hf((size_t)B * 256 * D), img((size_t)3 * D * D);
     for (size_t i = 0; i < hb.size(); ++i) hb[i] = host_f2bf(h_host[i]);
     for (int b = 0; b < B; ++b)          // the patch rows in fragment order (what the fused block tail writes: MlpFusedArgs::ln_out_frag)
         for (int n = 0; n < 256; ++n)
             for (int k = 0; k < D; ++k)
                 hf[((((size_t)b * 8 + n / 32) * (D / 16) + k / 16) * 64 + (n % 32) + 32 * ((k % 16) / 8)) * 8 + k % 8] = hb[((size_t)b * L + extras + n) * D + k];
     qkv_attention_pack(D, H, wqkv, host_f2bf, img.data());
-    auto bf = [](unsigned short v) { unsigned u = (unsigned)v << 16; float f; std::memcpy(&f, &u, 4); return f; };
-    // the extra-token rows' qkv, as qkv_rows_kernel leaves it (bf16 operands, fp32 sum, bf16 result; head-major)
-    for (int b = 0; b < B; ++b)
-        for (int e = 0; e < extras; ++e)
-            for (int col = 0; col < 3 * D; ++col) {
-                double acc = bqkv ? bqkv[col] : 0.0;
-                for (int k = 0; k < D; ++k) acc += (double)bf(hb[((size_t)b * L + e) * D + k]) * (double)bf(host_f2bf(wqkv[(size_t)col * D + k]));
-                q[(((size_t)b * 3 * H + col / 64) * hm.Lp + e) * 64 + col % 64] = host_f2bf((float)acc);   // (dd_internal.h hm_offset)
-            }
     void *dH = nullptr, *dW = nullptr, *dB = nullptr, *dQ = nullptr, *dO = nullptr;
     auto cleanup = [&]() { for (void* p : {dH, dW, dB, dQ, dO}) if (p) (void)hipFree(p); };
 #define DD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(c, DD_ERR_HIP, hipGetErrorString(e_)); } } while (0)
-    DD_TRY(hipMalloc(&dH, hf.size() * 2)); DD_TRY(hipMalloc(&dW, img.size() * 2)); DD_TRY(hipMalloc(&dQ, q.size() * 2)); DD_TRY(hipMalloc(&dO, M * D * 2));
+    DD_TRY(hipMalloc(&dH, hf.size() * 2)); DD_TRY(hipMalloc(&dW, img.size() * 2)); DD_TRY(hipMalloc(&dQ, hb.size() * 2)); DD_TRY(hipMalloc(&dO, M * D * 2));
     DD_TRY(hipMemcpy(dH, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
     DD_TRY(hipMemcpy(dW, img.data(), img.size() * 2, hipMemcpyHostToDevice));
-    DD_TRY(hipMemcpy(dQ, q.data(), q.size() * 2, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dQ, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));     // row-major norm1 rows: the kernel reads the extra-token rows of it
     DD_TRY(hipMemset(dO, 0, M * D * 2));
     if (bqkv) { DD_TRY(hipMalloc(&dB, (size_t)3 * D * 4)); DD_TRY(hipMemcpy(dB, bqkv, (size_t)3 * D * 4, hipMemcpyHostToDevice)); }
     DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, (bf16_t*)dO, B, L, H, D, extras, s));

@@ -182,11 +182,11 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
 // attn.qkv + attention in one launch (attention.hip qkv_attention_kernel): h = norm1 of the patch rows in fragment order
-// (MlpFusedArgs::ln_out_frag); wimg from qkv_attention_pack;
-// qkv = the head-major tensor holding the extra-token rows' q / k / v (launch_qkv_rows); bf16, D = 512, L = 256 + extras only
+// (MlpFusedArgs::ln_out_frag); hx = norm1 row-major [B L, D], of which the extra-token rows are read; wimg from qkv_attention_pack;
+// bf16, D = 512, L = 256 + extras only
 bool qkv_attention_supported(int D, int H, int L, int extras);
 void qkv_attention_pack(int D, int H, const float* w, unsigned short (*to_bf16)(float), unsigned short* img);
-hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* qkv, bf16_t* out,
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, bf16_t* out,
                                 int B, int L, int H, int D, int extras, hipStream_t s);
 
 struct FinalArgs {

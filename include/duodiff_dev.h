@@ -35,8 +35,7 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
 /* Development harness for the attention launch that computes attn.qkv itself (attention.hip qkv_attention_kernel; bf16, 8 heads
  * of 64, L = 256 patches + `extras` = 1 or 2 leading extra tokens): out = softmax(q k^T / 8) v per (image, head) with
  * q, k, v = split(h . wqkv^T + bqkv), from host arrays h [B L, 512] (rounded to bf16), wqkv [1536, 512], bqkv [1536] or NULL;
- * out_host bf16 [B L, 512].  The extra-token rows' qkv (the model makes it with a small launch of its own) is computed on the
- * host here.  `iters` timed launches -> ms_out. */
+ * out_host bf16 [B L, 512].  `iters` timed launches -> ms_out. */
 int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const float* h_host, const float* wqkv, const float* bqkv,
                          unsigned short* out_host, int iters, void* stream, float* ms_out);
 
