@@ -443,7 +443,10 @@ struct QkvAttnArgs {
     const bf16_t* h;       // norm1 of the patch rows in fragment order: [B * 8 groups of 32 rows][D / 16][64 lanes][8] (MlpFusedArgs::ln_out_frag)
     const bf16_t* wimg;    // [H][6 tiles][D / 16 k-steps][64 lanes][8] (qkv_attention_pack)
     const float* bias;     // [3 D] or nullptr
-    const bf16_t* hx;      // norm1 rows, row-major [B L, D]: only the extra-token rows (l < E) are read
+    const bf16_t* hx;      // norm1 rows, row-major [B L, D]: only the extra-token rows (l < E) are read -- or nullptr:
+    const float* xres;     //   then the kernel normalises those rows itself from the fp32 residual stream [B L, D]
+    const float* ln_g;     //   with this block's norm1 weight
+    const float* ln_b;     //   and bias (reference models/uvit.py:206, eps 1e-5, two-pass statistics in fp32)
     bf16_t* out;           // [B L, D]
     int B, L, H, Lp, E;
 };
@@ -499,7 +502,26 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     dma_tile(0);
 
     // ---- the extra tokens' rows of h into LDS (every wave reads its k range of them in every tile); zero rows behind the images' last
-    if (tid < E * 64) *reinterpret_cast<f32x4*>(hxl + tid * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + (tid >> 6)) * D + (tid & 63) * 8);
+    if (a.hx) {
+        if (tid < E * 64) *reinterpret_cast<f32x4*>(hxl + tid * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + (tid >> 6)) * D + (tid & 63) * 8);
+    } else if (wave < E) {     // wave e normalises extra row e: 8 columns per lane
+        const float* xr = a.xres + ((long long)b * L + wave) * D + lane * 8;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+        float s1 = (x0[0] + x0[1]) + (x0[2] + x0[3]) + (x1[0] + x1[1]) + (x1[2] + x1[3]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o);
+        const float mean = s1 / (float)D;
+        const f32x4 d0 = x0 - mean, d1 = x1 - mean;
+        float s2 = (d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3]) + (d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+        const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + lane * 8 + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * 8), c1 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * 8 + 4);
+        const f32x4 y0 = d0 * rstd * g0 + c0, y1 = d1 * rstd * g1 + c1;
+        *reinterpret_cast<uint4*>(hxl + wave * (D * 2) + lane * 16) =
+            uint4{pack2_bf16(y0[0], y0[1]), pack2_bf16(y0[2], y0[3]), pack2_bf16(y1[0], y1[1]), pack2_bf16(y1[2], y1[3])};
+    }
     for (int i = tid; i < (kLP - 256 - E) * 16; i += 512) {
         const int r = 256 + E + (i >> 4), c = i & 15;
         *reinterpret_cast<f32x4*>((c < 8 ? Ks : Vt) + r * 128 + (c & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -698,10 +720,10 @@ bool qkv_attention_supported(int D, int H, int L, int extras) {
 
 static size_t qkv_attention_lds(int D) { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaAuxBytes + (size_t)2 * (D / 16) * 1024; }
 
-hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, bf16_t* out,
-                                int B, int L, int H, int D, int extras, hipStream_t s) {
-    if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || !hx || !out || B < 1) return hipErrorInvalidValue;
-    const QkvAttnArgs a{h, wimg, bias, hx, out, B, L, H, make_head_major(L, H).Lp, extras};
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, const float* xres,
+                                const float* ln_g, const float* ln_b, bf16_t* out, int B, int L, int H, int D, int extras, hipStream_t s) {
+    if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || (!hx && (!xres || !ln_g || !ln_b)) || !out || B < 1) return hipErrorInvalidValue;
+    const QkvAttnArgs a{h, wimg, bias, hx, xres, ln_g, ln_b, out, B, L, H, make_head_major(L, H).Lp, extras};
     hipLaunchKernelGGL((qkv_attention_kernel<512>), dim3(B * H), dim3(512), qkv_attention_lds(512), s, a);
     return hipGetLastError();
 }

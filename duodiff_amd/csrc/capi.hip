@@ -438,7 +438,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         h_ready = false;
         if (qa_ready) {
             if constexpr (sizeof(T) == 2)
-                DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, (const bf16_t*)h, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
+                DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, nullptr, m->x, w.ln1_g, w.ln1_b, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
         } else {
             if (!qkv_done) {
                 GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
@@ -508,12 +508,17 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     MlpFusedArgs fr = fa;                    // the reduce kernel finishes y of the extra-token rows (fp32 + the bf16
                     fr.ln_out = nullptr;                     // copy in xb); their skip_linear + norm1 follow in one small launch
                     DD_HIP(c, launch_mlp_reduce(fr, D, s));
-                    DD_HIP(c, launch_skip_rows_ln(fa, D, s));
+                    // (fused_qa: the attention launch normalises the extra-token rows itself, so the launch is split by columns)
+                    DD_HIP(c, launch_skip_rows_ln(fa, D, s, !qa_next));
+                } else if (qa_next) {
+                    MlpFusedArgs fr = fa;
+                    fr.ln_out = nullptr;                     // (ditto: no norm1 rows needed)
+                    DD_HIP(c, launch_mlp_reduce(fr, D, s));
                 } else {
                     DD_HIP(c, launch_mlp_reduce(fa, D, s));
                 }
                 if (qkv_next) DD_HIP(c, launch_qkv_rows(fa, D, s));   // the extra-token rows' qkv, from the norm1 rows the launch above wrote
-                qa_ready = qa_next;    // (the extra-token rows' norm1 is in h, row-major: the reduce / skip_rows launch above wrote it)
+                qa_ready = qa_next;    // (the extra-token rows reach the attention launch through the residual stream x)
                 continue;
             }
         }
@@ -1501,14 +1506,14 @@ int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float
     DD_TRY(hipMemcpy(dQ, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));     // row-major norm1 rows: the kernel reads the extra-token rows of it
     DD_TRY(hipMemset(dO, 0, M * D * 2));
     if (bqkv) { DD_TRY(hipMalloc(&dB, (size_t)3 * D * 4)); DD_TRY(hipMemcpy(dB, bqkv, (size_t)3 * D * 4, hipMemcpyHostToDevice)); }
-    DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, (bf16_t*)dO, B, L, H, D, extras, s));
+    DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, nullptr, nullptr, nullptr, (bf16_t*)dO, B, L, H, D, extras, s));
     DD_TRY(hipStreamSynchronize(s));
     DD_TRY(hipMemcpy(out_host, dO, M * D * 2, hipMemcpyDeviceToHost));
     if (iters > 0 && ms_out) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, (bf16_t*)dO, B, L, H, D, extras, s));
+        for (int i = 0; i < iters; ++i) DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, nullptr, nullptr, nullptr, (bf16_t*)dO, B, L, H, D, extras, s));
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -139,7 +139,7 @@ void mlp_fused_pack_rows(int D, int nrows, const float* w, unsigned short (*to_b
 hipError_t launch_qkv_rows(const MlpFusedArgs& a, int D, hipStream_t s);
 void mlp_fused_pack_proj(int D, const float* wp, unsigned short (*to_bf16)(float), unsigned short* img);
 void mlp_fused_pack_skip(int D, const float* ws, unsigned short (*to_bf16)(float), unsigned short* img);
-hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s);
+hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s, bool with_ln = true);   // with_ln = false: x' only, column-split (D = 512)
 size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
 void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
@@ -182,12 +182,13 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 template <typename T>
 hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hipStream_t s);
 // attn.qkv + attention in one launch (attention.hip qkv_attention_kernel): h = norm1 of the patch rows in fragment order
-// (MlpFusedArgs::ln_out_frag); hx = norm1 row-major [B L, D], of which the extra-token rows are read; wimg from qkv_attention_pack;
+// (MlpFusedArgs::ln_out_frag); the extra-token rows: hx = norm1 row-major [B L, D], or hx = nullptr and xres / ln_g / ln_b = the fp32
+// residual stream and this block's norm1 parameters (the kernel normalises the rows itself); wimg from qkv_attention_pack;
 // bf16, D = 512, L = 256 + extras only
 bool qkv_attention_supported(int D, int H, int L, int extras);
 void qkv_attention_pack(int D, int H, const float* w, unsigned short (*to_bf16)(float), unsigned short* img);
-hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, bf16_t* out,
-                                int B, int L, int H, int D, int extras, hipStream_t s);
+hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, const float* xres,
+                                const float* ln_g, const float* ln_b, bf16_t* out, int B, int L, int H, int D, int extras, hipStream_t s);
 
 struct FinalArgs {
     const float* dec;      // [B*L, pd] decoder_pred output for every token (extras included)

@@ -1116,10 +1116,14 @@ __global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
 // D = 512, as two chains), the rows' y and skip operands parked once in LDS (padded rows: conflict-free fragment reads; the
 // y half is read in accumulator k order as two 8-byte pieces per k-step), the weights straight from the image's fragment
 // order, 16 fragments in flight per wave, LayerNorm statistics (two-pass) exchanged through LDS.
-template <int D>
-__global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs a) {
+// WPG = waves (= column tiles) per workgroup.  WPG == D / 32 with LN: the form above.  WPG < D / 32 without LN (grid.y = D / 32 / WPG
+// column groups): the product's form where the consumer normalises the rows itself (qkv_attention_kernel) -- a workgroup then reads
+// WPG x 2 D x 64 bytes of weights instead of all 2 D^2 x 2, which is what the launch's time is (a CU's L2 port: 1 MB ~ 15 us).
+template <int D, int WPG = D / 32, bool LN = true>
+__global__ void __launch_bounds__(WPG * 64) skip_rows_ln_kernel(const MlpFusedArgs a) {
     using C = MlpCfg<D>;
-    constexpr int H2 = C::F / 2, PITCH = D * 2 + 16, NW = C::NT;
+    static_assert(!LN || WPG == D / 32, "LayerNorm needs the whole row in one workgroup");
+    constexpr int H2 = C::F / 2, PITCH = D * 2 + 16, NW = C::NT, NTHR = WPG * 64;
     extern __shared__ __attribute__((aligned(16))) char srl[];
     char* ybuf = srl;                       // [32][PITCH]
     char* sbuf = srl + 32 * PITCH;          // [32][PITCH]
@@ -1130,17 +1134,38 @@ __global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs 
         return (long long)b * a.tok_l + (q - b * a.tok_e);
     };
     // ---- park the operand rows: 32 rows x D bf16 each, 16-byte chunks
-    constexpr int CPR = D / 8, ITEMS = 2 * 32 * CPR, PER = (ITEMS + D * 2 - 1) / (D * 2);
+    constexpr int CPR = D / 8, ITEMS = 2 * 32 * CPR, PER_ALL = (ITEMS + NTHR - 1) / NTHR, PER = PER_ALL < 8 ? PER_ALL : 8, ROUNDS = (PER_ALL + PER - 1) / PER;
     f32x4 stg[PER];
+    auto stage_load = [&](int rd) {
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int it = tid + k * (D * 2), which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
-        const long long row = row_of(blockIdx.x * 32 + r);
-        const bf16_t* src = which == 0 ? a.out + row * a.ldo : a.skip + row * D;
-        stg[k] = it < ITEMS ? *reinterpret_cast<const f32x4*>(src + ch * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < PER; ++k) {
+            const int it = tid + (rd * PER + k) * NTHR, which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
+            const long long row = row_of(blockIdx.x * 32 + r);
+            const bf16_t* src = which == 0 ? a.out + row * a.ldo : a.skip + row * D;
+            stg[k] = it < ITEMS ? *reinterpret_cast<const f32x4*>(src + ch * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_store = [&](int rd) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int it = tid + (rd * PER + k) * NTHR, which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
+            if (it < ITEMS) *reinterpret_cast<f32x4*>((which == 0 ? ybuf : sbuf) + r * PITCH + ch * 16) = stg[k];
+        }
+    };
+    constexpr bool DMA_PARK = !LN && D == 512;     // a row = exactly one 1 KB LDS-DMA piece: all 64 pieces of the workgroup in flight at once
+    if constexpr (DMA_PARK) {                      // (the register-staged rounds below are a chain of memory round trips at 128 threads)
+#pragma unroll
+        for (int i = 0; i < 32 / WPG; ++i) {
+            const int r = wave + i * WPG;
+            const long long row = row_of(blockIdx.x * 32 + r);
+            glds16(a.out + row * a.ldo + lane * 8, ybuf + r * PITCH);
+            glds16(a.skip + row * D + lane * 8, sbuf + r * PITCH);
+        }
+    } else {
+        stage_load(0);
     }
     // this wave's column tile: weights of the y half (block t), first fragments requested before the operands are parked
-    const int t = wave;
+    const int t = blockIdx.y * WPG + wave;
     const char* const wskip = a.wimg + ((size_t)a.nproj + 2 * (size_t)a.nchunks) * C::BLK;
     const bf16x8* wy = reinterpret_cast<const bf16x8*>(wskip + (size_t)t * C::BLK) + lane;
     const bf16x8* ws0 = reinterpret_cast<const bf16x8*>(wskip + (size_t)(C::NT + t / 2) * C::BLK) + (t & 1) * H2 * 64 + lane;
@@ -1153,10 +1178,12 @@ __global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs 
     bf16x8 wf[G];
 #pragma unroll
     for (int f = 0; f < G; ++f) wf[f] = wfrag(f);
+    if constexpr (DMA_PARK) {
+        wait_vmcnt<0>();
+    } else {
+        stage_store(0);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int it = tid + k * (D * 2), which = it / (32 * CPR), rem = it % (32 * CPR), r = rem / CPR, ch = rem % CPR;
-        if (it < ITEMS) *reinterpret_cast<f32x4*>((which == 0 ? ybuf : sbuf) + r * PITCH + ch * 16) = stg[k];
+        for (int rd = 1; rd < ROUNDS; ++rd) { stage_load(rd); stage_store(rd); }
     }
     __syncthreads();
     f32x16 acc0, acc1;
@@ -1184,6 +1211,15 @@ __global__ void __launch_bounds__(D * 2) skip_rows_ln_kernel(const MlpFusedArgs 
         if (kk + G < 2 * C::F) wf[kk % G] = wfrag(kk + G);
     }
     const f32x16 acc = acc0 + acc1;
+    if constexpr (!LN) {
+        const int idx = blockIdx.x * 32 + r32;
+        if (idx >= a.n_extra) return;
+        const long long row = row_of(idx);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(a.xres + row * D + 32 * t + 8 * g + 4 * h) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        return;
+    }
     // two-pass LayerNorm statistics over the row's D columns: lane halves via shuffle, the waves via LDS
     float s1 = 0.f;
 #pragma unroll
@@ -1452,6 +1488,8 @@ hipError_t init_mlp_fused_kernels() {
         e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(DV));
     DD_ATTR_P(128) DD_ATTR_P(256) DD_ATTR_P(512)
 #undef DD_ATTR_P
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<512, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(512));
     return e;
 }
 
@@ -1470,11 +1508,16 @@ hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
 }
 
 // skip_linear + norm1 of the extra-token rows of a SKIP launch (after launch_mlp_reduce, which stored their y in a.out); no-op without extras
-hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s) {
+hipError_t launch_skip_rows_ln(const MlpFusedArgs& a, int D, hipStream_t s, bool with_ln) {
     if (a.n_extra <= 0 || a.nskip <= 0) return hipSuccess;
-    if (!a.out || !a.skip || !a.bskip || !a.ln_out || !a.ln_out_g || !a.ln_out_b) return hipErrorInvalidValue;
-    const dim3 grid((a.n_extra + 31) / 32);
+    if (!a.out || !a.skip || !a.bskip || (with_ln && (!a.ln_out || !a.ln_out_g || !a.ln_out_b))) return hipErrorInvalidValue;
     const size_t lds = skip_rows_lds(D);
+    if (!with_ln) {     // column-split form: 2 column tiles per workgroup (the consumer normalises the rows)
+        if (D != 512) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((skip_rows_ln_kernel<512, 2, false>), dim3((a.n_extra + 31) / 32, 512 / 32 / 2), dim3(128), lds, s, a);
+        return hipGetLastError();
+    }
+    const dim3 grid((a.n_extra + 31) / 32);
     switch (D) {
         case 128: hipLaunchKernelGGL((skip_rows_ln_kernel<128>), grid, dim3(256), lds, s, a); break;
         case 256: hipLaunchKernelGGL((skip_rows_ln_kernel<256>), grid, dim3(512), lds, s, a); break;
