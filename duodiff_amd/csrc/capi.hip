@@ -434,7 +434,16 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
         }
         skip_done = false;
-        if (!h_ready && !qkv_done) DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));   // else: written by the previous block's fused MLP
+        if (!h_ready && !qkv_done) {     // else: written by the previous block's fused MLP
+            if (sizeof(T) == 2 && m->fused_qa) {
+                // (the first block; blocks behind a skip_linear GEMM when that fusion is off) norm1 straight into the order the
+                // attention launch loads it, so that these blocks take the same launch as the others
+                DD_HIP(c, launch_layernorm_frag(m->x, w.ln1_g, w.ln1_b, (bf16_t*)h, m->hfrag, M, D, L, m->extras, s));
+                qa_ready = true;
+            } else {
+                DD_HIP(c, launch_layernorm<T>(m->x, w.ln1_g, w.ln1_b, h, M, D, s));
+            }
+        }
         h_ready = false;
         if (qa_ready) {
             if constexpr (sizeof(T) == 2)

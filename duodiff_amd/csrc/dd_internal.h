@@ -177,6 +177,8 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s);
 template <typename T>
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, T* out,
                             int rows, int D, hipStream_t s);
+hipError_t launch_layernorm_frag(const float* x, const float* gamma, const float* beta, bf16_t* out, bf16_t* frag, int rows, int D,
+                                 int tok_l, int tok_e, hipStream_t s);   // patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
 
 // qkv: head-major (HeadMajor, make_head_major(L, H)); out: [B * L, D] rows
 template <typename T>

@@ -252,10 +252,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// frag != nullptr (bf16, D % 256 == 0, tok_n % 32 == 0): the patch rows (token l >= tok_e of every tok_l-row image) are written
+// THERE in MFMA B-fragment order -- [32-row group of patch rows][D / 16 k-steps][64 lanes] x 16 bytes, what the attention launch
+// that computes attn.qkv itself loads (MlpFusedArgs::ln_out_frag) -- instead of row-major; the extra-token rows still go to `out`.
 template <typename T>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out,
-                                                        int rows, int D) {
+                                                        int rows, int D, T* __restrict__ frag = nullptr, int tok_l = 0, int tok_e = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -285,6 +288,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         if (j < per) { const float dlt = v[j] - mean; q2 += dlt * dlt; }
     const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + 1e-5f);
     T* orow = out + (long long)row * D;
+    bool to_frag = false;
+    if constexpr (sizeof(T) == 2) {
+        if (frag) {
+            const int b = row / tok_l, l = row - b * tok_l;
+            if (l >= tok_e) {
+                const int n = l - tok_e, grp = b * ((tok_l - tok_e) / 32) + n / 32;
+                orow = frag + ((long long)grp * (D / 16) * 64 + (n & 31)) * 8;
+                to_frag = true;
+            }
+        }
+    }
     if ((D & 255) == 0) {
 #pragma unroll
         for (int j = 0; j < kLnMaxPerLane / 4; ++j) {
@@ -296,8 +310,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o4[e] = Elem<T>::from_f32((v[j * 4 + e] - mean) * rstd * gq[e] + bq[e]);
-                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(orow + c0) = *reinterpret_cast<const uint2*>(o4);
-                else *reinterpret_cast<f32x4*>(orow + c0) = *reinterpret_cast<const f32x4*>(o4);
+                if constexpr (sizeof(T) == 2) {
+                    // fragment order: columns c0 .. c0+3 = k-step c0 / 16, lane half (c0 / 8) & 1, elements c0 & 7 ..
+                    const long long off = to_frag ? ((long long)(c0 >> 4) * 64 + 32 * ((c0 >> 3) & 1)) * 8 + (c0 & 7) : c0;
+                    *reinterpret_cast<uint2*>(orow + off) = *reinterpret_cast<const uint2*>(o4);
+                } else {
+                    *reinterpret_cast<f32x4*>(orow + c0) = *reinterpret_cast<const f32x4*>(o4);
+                }
             }
         }
     } else {
@@ -746,7 +765,14 @@ template <typename T>
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows,
                             int D, hipStream_t s) {
     if (D % 64 || D > 64 * kLnMaxPerLane) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, D);
+    hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, D, (T*)nullptr, 0, 0);
+    return hipGetLastError();
+}
+// the patch rows in MFMA fragment order into `frag` (see layernorm_kernel), the extra-token rows row-major into `out`
+hipError_t launch_layernorm_frag(const float* x, const float* gamma, const float* beta, bf16_t* out, bf16_t* frag, int rows, int D,
+                                 int tok_l, int tok_e, hipStream_t s) {
+    if (D % 256 || D > 64 * kLnMaxPerLane || !frag || tok_l <= tok_e || (tok_l - tok_e) % 32 || rows % tok_l) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, D, frag, tok_l, tok_e);
     return hipGetLastError();
 }
 template hipError_t launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
