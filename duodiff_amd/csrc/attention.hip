@@ -534,7 +534,6 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     for (int j = 0; j < 6; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile j have landed (hipcc does not track LDS-DMA writes)
         __syncthreads();                                    // ... everyone's have, and nobody still reads the slot tile j + 1 goes to
-        if (j + 1 < 6) dma_tile(j + 1);
         const char* wb = ring + (j & 1) * BLK + lane * 16;
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // weight fragments four k-steps ahead of their MFMAs (the reads go out BEFORE the pair of MFMAs two steps older: hipcc
@@ -553,6 +552,12 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
             __builtin_amdgcn_sched_barrier(0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks + 1], acc1, 0, 0, 0);
+            // the next tile's DMA requests, one per MFMA pair from the second pair on: their issue cost (~70 clocks each) then sits in
+            // the shadow of this wave's and its SIMD neighbour's MFMAs instead of in front of the tile
+            if (j + 1 < 6 && ks >= 2 && ks / 2 - 1 < PPW) {
+                const int p = wave * PPW + (ks / 2 - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)(j + 1) * BLK + p * 1024), (lptr_t)(ring + ((j + 1) & 1) * BLK + p * 1024), 16, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x16 acc = acc0 + acc1;
