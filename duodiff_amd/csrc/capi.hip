@@ -548,7 +548,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     // free here), then decoder_pred as an exact-fp32 MFMA GEMM in BOTH precision modes, so eps is
     // never rounded to bf16.  dec holds all L tokens per image; the extras are skipped downstream.
     if (m->wdec_g) {   // fused: rows read once, normalised rows never written
-        HeadDecArgs ha{m->x, m->wdec_g, m->dec_c, m->dec, M, m->pd};
+        HeadDecArgs ha{m->x, m->wdec_g, m->dec_c, m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};   // (only the patch rows)
         DD_HIP(c, launch_head_dec(ha, D, c->num_cus, s));
         return DD_OK;
     }

@@ -216,6 +216,7 @@ struct HeadDecArgs {
     const float* c;    // [pd]
     float* dec;        // [Mp, pd]
     int M, pd;
+    int tok_l, tok_e;  // > 0: rows are images of tok_l tokens whose first tok_e (the extra tokens) are NOT decoded; 0: every row
 };
 bool head_dec_supported(int D, int pd);
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s);

@@ -814,9 +814,13 @@ __global__ void __launch_bounds__(512) head_dec_kernel(const HeadDecArgs a) {
     // 16-row units dealt to the waves of the whole grid, unit u -> wave (u / grid) % 8 of workgroup u % grid: with
     // M = B (256 + extras) rows the few units beyond one per wave land on different CUs (128-row tiles per workgroup
     // left one workgroup for a second round of the whole launch).  Nothing below synchronises across waves.
-    const int units = (a.M + 15) / 16, stride = 8 * (int)gridDim.x;
+    // tok_l > 0: only the patch rows (tokens l >= tok_e of every tok_l-row image; 16 | tok_l - tok_e) are decoded -- the extra tokens'
+    // rows of dec are never read (unpatchify takes the patch tokens, reference models/uvit.py:379-381) and at B = 128 those 128 rows
+    // were 8 units more than one per wave: a second round of the whole launch on 8 CUs
+    const int upi = a.tok_l > 0 ? (a.tok_l - a.tok_e) / 16 : 0;                       // units per image
+    const int units = a.tok_l > 0 ? (a.M / a.tok_l) * upi : (a.M + 15) / 16, stride = 8 * (int)gridDim.x;
     for (int u = wave * (int)gridDim.x + (int)blockIdx.x; u < units; u += stride) {
-        const long long row = (long long)u * 16 + n;
+        const long long row = a.tok_l > 0 ? (long long)(u / upi) * a.tok_l + a.tok_e + (u % upi) * 16 + n : (long long)u * 16 + n;
         const bool ok = row < a.M;
         const f32x4* wlp = wl + lane;
         asm volatile("" : "+v"(wlp));   // opaque per unit: the LDS fragment reads are loop-invariant and hipcc would hoist all of them (spills)
@@ -870,6 +874,7 @@ bool head_dec_supported(int D, int pd) { return (D == 256 || D == 512) && pd >= 
 
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s) {
     if (!head_dec_supported(D, a.pd) || a.M < 1) return hipErrorInvalidValue;
+    if (a.tok_l > 0 && (a.tok_e < 0 || a.tok_e >= a.tok_l || (a.tok_l - a.tok_e) % 16 || a.M % a.tok_l)) return hipErrorInvalidValue;
     const int nt = (a.pd + 15) / 16;
     const int wgs = (a.M + 127) / 128;
     const dim3 grid((unsigned)(wgs < num_cus ? wgs : num_cus));     // one workgroup per CU (LDS), 16-row units dealt inside
