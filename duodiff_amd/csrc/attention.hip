@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     else { b = blockIdx.x / a.H; hh = blockIdx.x % a.H; }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, r32 = lane & 31;
-    const int L = a.L, E = a.E, H = a.H;
+    const int L = a.L, E = a.E;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
