@@ -130,6 +130,7 @@ struct MlpFusedArgs {
     int tok_n, tok_e, tok_l;
     int n_main, n_extra;   // B * tok_n patch rows (main tiles), B * tok_e extra rows (hidden-split tiles)
     int tiles_main, tiles_left, groups, cpg;
+    int prows;             // rows per hidden-split tile (32, 64 or 128: whole waves)
 };
 bool mlp_fused_supported(int D, int hidden);
 size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip, bool with_qkv);

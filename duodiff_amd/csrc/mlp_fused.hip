@@ -291,13 +291,14 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     auto row_of = [&](bool& ok) -> long long {
         unsigned l = (unsigned)threadIdx.x;
         asm volatile("" : "+v"(l));
-        const int idx = tile_idx * 128 + (int)l / 64 * 32 + ((int)l & 31);
+        const int local = (int)l / 64 * 32 + ((int)l & 31);
+        const int idx = tile_idx * (PARTIAL ? a.prows : 128) + local;      // (hidden-split tiles hold prows <= 128 rows: waves beyond them idle along)
         if constexpr (!PARTIAL) {
             ok = idx < a.n_main;
             const int p = ok ? idx : 0, b = p / a.tok_n;
             return (long long)b * a.tok_l + a.tok_e + (p - b * a.tok_n);
         } else {
-            ok = idx < a.n_extra;
+            ok = local < a.prows && idx < a.n_extra;
             const int q = ok ? idx : 0, b = q / a.tok_e;
             return (long long)b * a.tok_l + (q - b * a.tok_e);
         }
@@ -763,7 +764,8 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     // (SKIP: the accumulators hold x' = skip_linear([y | skip]) complete with its bias; no bf16 copy of it is needed)
     const int he = half_of();
     if constexpr (PARTIAL) {
-        float* pp = a.partial + ((long long)slab * 128 + wave * 32 + r32) * D + 4 * he;
+        if (wave * 32 >= a.prows) return;          // (this wave's rows lie past the tile: nothing to store, no barrier follows)
+        float* pp = a.partial + ((long long)slab * a.prows + wave * 32 + r32) * D + 4 * he;
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             const f32x16 yt = Y[t];
@@ -992,7 +994,7 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // logical extra row
     if (r >= a.n_extra) return;
-    const int lt = (int)(r / 128), rr = (int)(r % 128);
+    const int lt = (int)(r / a.prows), rr = (int)(r % a.prows);
     const long long b = r / a.tok_e;
     const long long row = b * a.tok_l + (r - b * a.tok_e);
     const int col = lane * VPL;
@@ -1005,7 +1007,7 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
     float pv[kGroups][VPL];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-        const float* pp = a.partial + (((long long)lt * a.groups + (g < a.groups ? g : 0)) * 128 + rr) * D + col;
+        const float* pp = a.partial + (((long long)lt * a.groups + (g < a.groups ? g : 0)) * a.prows + rr) * D + col;
 #pragma unroll
         for (int e = 0; e < VPL; ++e) pv[g][e] = pp[e];
     }
@@ -1412,7 +1414,11 @@ void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, M
     a.n_main = B * n_patches;
     a.n_extra = B * extras;
     a.tiles_main = (a.n_main + 127) / 128;
-    a.tiles_left = (a.n_extra + 127) / 128;
+    // The hidden-split tiles run behind the main ones with the whole chip free, and their cost is what ONE workgroup moves through
+    // its CU's L2 port (rows in, weights, slab out): 32-row tiles (one wave's rows; the other three waves share the weight DMA and
+    // idle along) quarter the row and slab share of that -- 4 x the workgroups cost nothing there.
+    a.prows = 32;
+    a.tiles_left = (a.n_extra + a.prows - 1) / a.prows;
     int g = nchunks / 2 < kGroups ? nchunks / 2 : kGroups;                   // >= 2 chunks per group (the kernel unrolls by 2)
     if (g < 1) g = 1;
     a.cpg = ((nchunks + g - 1) / g + 1) & ~1;
@@ -1422,7 +1428,7 @@ void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, M
 size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden) {
     MlpFusedArgs a{};
     mlp_fused_plan(max_batch, 1, extras, 1 + extras, hidden, a);
-    return (size_t)a.tiles_left * a.groups * 128 * D * sizeof(float);
+    return (size_t)a.tiles_left * a.groups * a.prows * D * sizeof(float);
 }
 
 // Host: nn.Linear weights (fp32, [out, in]) -> the fragment-ordered bf16 image the kernel streams + permuted fc1 bias.
