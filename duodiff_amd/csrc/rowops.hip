@@ -155,18 +155,19 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
         const float* brow = a.bias + 4 * kq;
         const f32x4* wlp = wl + lane;
         // pos_embed / bias quads of pair p + 1 are requested before pair p computes (a load behind every iteration's
-        // stores would expose one L2 round trip per pair)
-        f32x4 pe = *reinterpret_cast<const f32x4*>(prow), po = *reinterpret_cast<const f32x4*>(prow + 16);
-        f32x4 be = *reinterpret_cast<const f32x4*>(brow), bo = *reinterpret_cast<const f32x4*>(brow + 16);
-        for (int p = 0; p < NP; ++p) {
+        // stores would expose one L2 round trip per pair).  The loop is unrolled by two with two register sets: rotating one set
+        // (cur = next; next = load) compiles into copies of the freshly loaded registers at the END of the iteration that issued
+        // the loads -- a vmcnt(0) per pair, i.e. exactly the exposed round trip the prefetch is there to hide (2 us x 16 pairs).
+        struct Quads { f32x4 pe, po, be, bo; };
+        auto fetch = [&](int pp) -> Quads {
+            return Quads{*reinterpret_cast<const f32x4*>(prow + 32 * pp), *reinterpret_cast<const f32x4*>(prow + 32 * pp + 16),
+                         *reinterpret_cast<const f32x4*>(brow + 32 * pp), *reinterpret_cast<const f32x4*>(brow + 32 * pp + 16)};
+        };
+        auto pair = [&](int pp, const Quads& q) {
             f32x4 acc_e = {0.f, 0.f, 0.f, 0.f}, acc_o = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 pe_c = pe, po_c = po, be_c = be, bo_c = bo;
-            const int pn = p + 1 < NP ? p + 1 : p;
-            pe = *reinterpret_cast<const f32x4*>(prow + 32 * pn); po = *reinterpret_cast<const f32x4*>(prow + 32 * pn + 16);
-            be = *reinterpret_cast<const f32x4*>(brow + 32 * pn); bo = *reinterpret_cast<const f32x4*>(brow + 32 * pn + 16);
 #pragma unroll
             for (int kk4 = 0; kk4 < KK4; ++kk4) {
-                const f32x4 we = wlp[((2 * p) * KK4 + kk4) * 64], wo = wlp[((2 * p + 1) * KK4 + kk4) * 64];
+                const f32x4 we = wlp[((2 * pp) * KK4 + kk4) * 64], wo = wlp[((2 * pp + 1) * KK4 + kk4) * 64];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (4 * kk4 + j < KK) {
@@ -177,8 +178,15 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
             }
             // lane (n, kq) holds columns 32 p + 4 kq + {0..3} (even tile) and 32 p + 16 + 4 kq + {0..3} (odd tile) of token n:
             // the four lanes of a token write 64 contiguous bytes per store, the two stores one 128-byte line
-            *reinterpret_cast<f32x4*>(xrow + 32 * p) = (acc_e + be_c) + pe_c;
-            *reinterpret_cast<f32x4*>(xrow + 32 * p + 16) = (acc_o + bo_c) + po_c;
+            *reinterpret_cast<f32x4*>(xrow + 32 * pp) = (acc_e + q.be) + q.pe;
+            *reinterpret_cast<f32x4*>(xrow + 32 * pp + 16) = (acc_o + q.bo) + q.po;
+        };
+        Quads qa = fetch(0), qb = qa;
+        for (int p = 0; p < NP; p += 2) {        // (NP = D / 32 is even: D is a multiple of 64)
+            qb = fetch(p + 1);
+            pair(p, qa);
+            qa = fetch(p + 2 < NP ? p + 2 : p + 1);
+            pair(p + 1, qb);
         }
     }
     if (((blockIdx.x * 8) & 15) == 0 && (int)(blockIdx.x * 8) / 16 < a.B) {   // the image's extra tokens: [label,] time (reference models/uvit.py:356-365)
