@@ -1062,7 +1062,9 @@ __global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
     constexpr int IPITCH = 1024 + 32;          // LDS pitch per instruction: 16-byte reads of consecutive rows spread over the banks
     extern __shared__ __attribute__((aligned(16))) char strip_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int t = blockIdx.x, idx0 = blockIdx.y * 128 + wave * 32;
+    // (launched with ONE wave per workgroup: the waves never talk to each other, and a workgroup's cost is what it pulls through its
+    // CU's L2 port -- 32 rows + the 32 KB weight block instead of 128 rows + the block)
+    const int t = blockIdx.x, idx0 = blockIdx.y * ((int)blockDim.x / 2) + wave * 32;
     char* strip = strip_lds + wave * (NI * IPITCH);
     auto row_of = [&](int idx) -> long long {
         const int q = idx < a.n_extra ? idx : a.n_extra - 1, b = q / a.tok_e;
@@ -1503,11 +1505,11 @@ hipError_t init_mlp_fused_kernels() {
 hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
     if (a.n_extra <= 0) return hipSuccess;
     if (a.nproj != D / 32 || !a.ao || !a.bproj) return hipErrorInvalidValue;
-    const dim3 grid(D / 32, (a.n_extra + 127) / 128);
+    const dim3 grid(D / 32, (a.n_extra + 31) / 32);
     switch (D) {
-        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(256), kProjRowsLds, s, a); break;
-        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(256), kProjRowsLds, s, a); break;
-        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(256), kProjRowsLds, s, a); break;
+        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
+        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
+        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
