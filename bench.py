@@ -38,7 +38,7 @@ from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PROFILE_DIR = REPO / "profiles" / "r03"     # committed rocprofv3 --pmc summaries (tools/collect_pmc.sh), keyed by build id
+PROFILE_DIR = REPO / "profiles" / "r04"     # committed rocprofv3 --pmc summaries (tools/collect_pmc.sh), keyed by build id
 
 # BASELINE.json configs[1], [3], [4]: (label, shallow yaml, full yaml, batch per GPU, CPU-baseline sample (images, steps))
 WORKLOADS = {
@@ -61,6 +61,7 @@ def parse(argv=None):
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_batch", type=int, default=0)
     p.add_argument("--cpu_steps", type=int, default=0)
+    p.add_argument("--launch_timeout", type=float, default=3000.0, help="--gpus N self-launch: seconds before the parent gives up and stops its ranks")
     p.add_argument("--dev_flags", type=int, default=0, help="dd_dev_set_flags value (include/duodiff_dev.h): same-process kernel-variant A/B runs only")
     return p.parse_args(argv)
 
@@ -122,38 +123,71 @@ def self_launch(a, argv):
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None, text=True))
     log(f"launched {a.gpus} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in (out0 or "").splitlines():      # rank 0's JSON line goes to stdout; anything a transport library printed there, to stderr
+    # rank 0's stdout is drained by a thread (a full pipe must not block it) while ALL children are polled: the first rank that
+    # exits non-zero takes the others down with it (they would otherwise sit in rendezvous / all_reduce until the
+    # torch.distributed timeout, holding their GPUs), and the whole launch is bounded by --launch_timeout
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + a.launch_timeout
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"ranks failed (rank, exit code): {bad}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = f"no result after {a.launch_timeout} s; still running: ranks {[r for r, c in enumerate(codes) if c is None]}"
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:                       # exactly the children started above, by pid
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    for line in ("".join(c or "" for c in chunks)).splitlines():   # rank 0's JSON line goes to stdout; anything a transport library printed there, to stderr
         print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    if failed:
+        raise SystemExit(f"bench.py: {failed}")
     return 0
 
 
-def committed_pmc(build_id):
-    """Counter values of the dominant kernel from the committed rocprofv3 --pmc summaries -- only if they were collected
-    on THIS build of the library (the summaries record dd_build_id()); otherwise (None, None, reason)."""
+def committed_pmc(build_id, workload, kernel_substr):
+    """Counter values of the dominant kernel from the committed rocprofv3 --pmc summaries of this workload -- only if they were
+    collected on THIS build of the library (the summaries record dd_build_id()); otherwise ({}, reason).
+    Returns {"traffic": HBM bytes per launch, "mfma_busy": MFMA-busy clocks / clocks of the launch, "sclk_mhz": clock held under it}."""
+    sfx = "" if workload == "celeba" else f"_{workload}"
     try:
-        pmc = json.load(open(PROFILE_DIR / "pmc_traffic.json"))
-        sq = json.load(open(PROFILE_DIR / "pmc_sq.json"))
+        pmc = json.load(open(PROFILE_DIR / f"pmc_traffic{sfx}.json"))
+        sq = json.load(open(PROFILE_DIR / f"pmc_sq{sfx}.json"))
     except Exception as e:
-        return None, None, f"no committed PMC profile under {PROFILE_DIR.relative_to(REPO)} ({type(e).__name__})"
+        return {}, f"no committed PMC profile of {workload} under {PROFILE_DIR.relative_to(REPO)} ({type(e).__name__})"
     have = pmc.get("_build_id"), sq.get("_build_id")
     if have[0] != build_id or have[1] != build_id:
-        return None, None, (f"committed PMC profile is of another build ({have[0]} / {have[1]}, running {build_id}): "
-                            "counters not quoted")
-    # the block tail runs as two instantiations (with / without the next block's skip_linear phases): the timed launches are a
-    # mix of both, so the counters are averaged over the profile's launches of either
-    ks = [v for n, v in pmc.items() if "mlp_fused_kernel" in n and isinstance(v, dict)]
+        return {}, (f"committed PMC profile is of another build ({have[0]} / {have[1]}, running {build_id}): counters not quoted")
+    # the dominant kernel may run as several instantiations (the block tail with / without the next block's skip_linear phases): the
+    # timed launches are a mix of them, so the counters are averaged over the profile's launches of all of them
+    ks = [v for n, v in pmc.items() if kernel_substr in n and isinstance(v, dict)]
     calls = sum(v["calls"] for v in ks)
     if not ks or not calls:
-        return None, None, "committed PMC profile holds no fused block-tail kernel"
-    traffic = sum((v["fetch_MB_corrected"] + v["write_MB"]) * v["calls"] for v in ks) / calls * 1e6
-    bs = [v for n, v in sq.items() if "mlp_fused_kernel" in n and isinstance(v, dict)]
-    busy = sum(v["mfma_clk_per_simd"] for v in bs) / sum(v["wave_clk"] for v in bs) if bs else None
-    return traffic, busy, None
+        return {}, f"committed PMC profile holds no {kernel_substr}"
+    out = {"traffic": sum((v["fetch_MB_corrected"] + v["write_MB"]) * v["calls"] for v in ks) / calls * 1e6}
+    bs = [v for n, v in sq.items() if kernel_substr in n and isinstance(v, dict) and v.get("gui_active_clk")]
+    if bs:   # launch-level: MFMA-busy clocks per SIMD / clocks the launch took (GRBM_GUI_ACTIVE / 8)
+        out["mfma_busy"] = sum(v["mfma_clk_per_simd"] for v in bs) / sum(v["gui_active_clk"] for v in bs)
+        out["sclk_mhz"] = sum(v["gui_active_clk"] for v in bs) / sum(v["avg_us_under_pmc"] for v in bs)
+    return out, None
 
 
 def main():
@@ -167,12 +201,17 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
                          "or run bench.py --gpus N without a torchrun environment (it then launches its ranks itself)")
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    no_device = (f"bench.py rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible on this node -- one process per GPU, "
+                 f"--gpus N needs N devices")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DUODIFF_DIST_BACKEND", "nccl")     # gloo: rehearsal / CPU test of the launch plumbing
         if backend == "nccl":
+            if ndev <= local_rank:
+                raise SystemExit(no_device)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -180,7 +219,9 @@ def main():
         log(f"process group initialised: rank {rank} of world {world}, backend {backend}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path (duodiff_amd._lib.EngineUnavailable)")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if ndev <= local_rank:
+        raise SystemExit(no_device)
+    torch.cuda.set_device(local_rank)
 
     from duodiff_amd import _lib, sampler
     from duodiff_amd.engine import sample_loop
@@ -231,13 +272,17 @@ def main():
     gathered = [torch.empty_like(imgs) for _ in range(world)] if world > 1 else None
     stream.wait_stream(torch.cuda.current_stream())   # x_T.clone() / allocations above ran on the default stream
 
+    ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def one_pass(n_steps, t_sw, t_stop):
         run(x, n_steps, t_sw, t_stop)
         ctx.to_images(x, out=imgs, stream=stream)
         if dist is not None:
             with torch.cuda.stream(stream):
                 if dist.get_backend() == "nccl":
+                    ev_g0.record()
                     dist.all_gather(gathered, imgs)              # the single collective: final images (RCCL over xGMI)
+                    ev_g1.record()
                 else:                                            # gloo rehearsal: host memory
                     stream.synchronize()
                     host = [torch.empty(imgs.shape) for _ in range(world)]
@@ -267,10 +312,13 @@ def main():
     dt = time.perf_counter() - t0
     timing = ctx.last_sample_timing()   # hipEvents around the K steps of this rank's dd_sample call
     on_dev = dist is None or dist.get_backend() == "nccl"
-    t_all = torch.tensor([dt, timing[0]], device=dev if on_dev else "cpu", dtype=torch.float64)
+    gather_ms = ev_g0.elapsed_time(ev_g1) if (dist is not None and dist.get_backend() == "nccl") else 0.0
+    # MAX over ranks of (wall, GPU ms of the K steps, all_gather ms, -GPU ms): the last entry gives the MIN, so that a slow or
+    # late rank shows in the one line rank 0 prints
+    t_all = torch.tensor([dt, timing[0], gather_ms, -timing[0]], device=dev if on_dev else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    dt, gpu_ms_max = float(t_all[0].item()), float(t_all[1].item())
+    dt, gpu_ms_max, gather_ms_max, gpu_ms_min = float(t_all[0].item()), float(t_all[1].item()), float(t_all[2].item()), -float(t_all[3].item())
     log(f"timed region done: {dt:.3f} s")
     finite = bool(torch.isfinite(imgs).all().item())
 
@@ -294,6 +342,7 @@ def main():
             # algorithmic bytes of one launch: fp32 residual rows read once and written once, the bf16 attention output read
             # once, bf16 copy for the long skip, bf16 norm1 output for the next block, the bf16 weights once
             alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2 + 2) + (2 * D_ * H_ + D_ * D_) * 2
+            pmc_kernel = "mlp_fused_kernel"
             kname = ("mlp_fused_kernel<%d>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d "
                      "(the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (D_, M_rows, D_, H_))
             # depth // 2 of the depth launches per step also run the NEXT block's skip_linear on the patch rows (cat[y, skip] . Wskip^T:
@@ -307,13 +356,13 @@ def main():
             M_rows = B * mp_f.seq_len
             fl = 2.0 * M_rows * D_ * H_
             alg_bytes = M_rows * D_ * 2 + M_rows * H_ * 2 + D_ * H_ * 2
+            pmc_kernel = "gemm256_kernel<1>"
             kname = "gemm256_kernel<EPI_BIAS_GELU>: fc1 + bias + exact-erf GELU, M=%d K=%d N=%d" % (M_rows, D_, H_)
         ach = fl / (ms * 1e-3) / 1e12
         # HBM bytes / MFMA-busy fraction of that kernel: quoted from the COMMITTED rocprofv3 --pmc profile only when that profile
         # was collected on the build that is running (rocprofv3 cannot run inside this process); null + reason otherwise
-        traffic, mfma_busy, why_not = (None, None, "PMC profile is collected for the headline workload only")
-        if a.workload == "celeba" and fused:
-            traffic, mfma_busy, why_not = committed_pmc(build_id)
+        pm, why_not = committed_pmc(build_id, a.workload, pmc_kernel)
+        traffic, mfma_busy, sclk = pm.get("traffic"), pm.get("mfma_busy"), pm.get("sclk_mhz")
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
         out = {
             "metric": "images/sec (whole node) DuoDiff 1000-step %s" % label,
@@ -328,7 +377,8 @@ def main():
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],
                        # wall time of the timed region (MAX over ranks) minus the slowest rank's GPU time of the K steps: output kernel,
                        # the all_gather, barriers, rank skew and host launch overhead together
-                       "non_step_ms": dt * 1000.0 - gpu_ms_max, "dev_flags": a.dev_flags,
+                       "non_step_ms": dt * 1000.0 - gpu_ms_max, "gpu_ms_total_max_over_ranks": gpu_ms_max, "gpu_ms_total_min_over_ranks": gpu_ms_min,
+                       "all_gather_ms_max_over_ranks": gather_ms_max if world > 1 else None, "dev_flags": a.dev_flags,
                        "library_build_id": build_id},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -341,7 +391,10 @@ def main():
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
                          "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "mfma_busy_frac_pmc": mfma_busy,
-                         "mfma_busy_source": (f"committed profile {PROFILE_DIR.relative_to(REPO)}/pmc_sq.json of this build; not measured in this run") if mfma_busy else why_not,
+                         "mfma_busy_source": (f"SQ_VALU_MFMA_BUSY_CYCLES per SIMD / (GRBM_GUI_ACTIVE / 8) of the launch, committed profile {PROFILE_DIR.relative_to(REPO)}/pmc_sq*.json "
+                                              f"of this build; not measured in this run") if mfma_busy else why_not,
+                         "sclk_mhz_under_load": sclk,
+                         "sclk_source": ("GRBM_GUI_ACTIVE / 8 / launch duration of the same committed profile (profiled passes clock 2-5 % below un-profiled ones)") if sclk else why_not,
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
                                            "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},

@@ -12,9 +12,9 @@ DD_PREC_BF16, DD_PREC_FP32 = 0, 1
 DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
 DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
 DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, DD_EE_ATTENTION_PROBE = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_EMBED, DD_DEV_MLP_EXTRAS_ONLY = 1, 2, 4, 8, 16
-DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV = 32, 64
+DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV, DD_DEV_NO_FUSED_QA = 32, 64, 128
 
 
 class dd_config(C.Structure):
@@ -35,7 +35,7 @@ class dd_affine_sample_args(C.Structure):
                 ("t", C.POINTER(C.c_float)), ("a", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
                 ("c", C.POINTER(C.c_float)), ("noise", C.POINTER(C.c_int32)), ("noise_mode", C.c_int32),
                 ("use_graph", C.c_int32), ("seed", C.c_uint64), ("y_dev", C.c_void_p), ("x_dev", C.c_void_p),
-                ("B", C.c_int32), ("reserved", C.c_int32)]
+                ("B", C.c_int32), ("counter_base", C.c_int32)]
 
 
 class dd_ee_sample_args(C.Structure):
@@ -114,11 +114,19 @@ def load():
         lib = C.CDLL(str(LIB_PATH))
     except OSError as e:  # e.g. libamdhip64 missing
         raise EngineUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    lib.dd_abi_version.restype = C.c_int
+    if lib.dd_abi_version() != ABI_VERSION:
+        raise EngineUnavailable(f"{LIB_PATH}: ABI version {lib.dd_abi_version()}, this package binds version {ABI_VERSION}; rebuild")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # the production surface (include/duodiff.h) must be complete; a library built without the development entry
+            # points (include/duodiff_dev.h: dd_dev_*), e.g. an A/B build of an older tree, still loads
+            if name.startswith("dd_dev_"):
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
-    if lib.dd_abi_version() != ABI_VERSION:
-        raise EngineUnavailable("libduodiff.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

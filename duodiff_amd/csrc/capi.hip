@@ -1185,6 +1185,7 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
     if (a->late && (rc = check_call(c, a->late, a->B, a->y_dev))) return rc;
     if (!a->x_dev || !a->t || !a->a || !a->b || !a->c || !a->noise) return fail(c, DD_ERR_INVALID, "null tensor / table");
     if (a->n_steps < 1 || a->n_steps > (1 << 20)) return fail(c, DD_ERR_INVALID, "n_steps outside [1, 2^20]");
+    if (a->counter_base < 0 || a->counter_base > (1 << 20)) return fail(c, DD_ERR_INVALID, "counter_base outside [0, 2^20]");
     if (a->noise_mode != DD_NOISE_PHILOX && a->noise_mode != DD_NOISE_NONE)
         return fail(c, DD_ERR_INVALID, "dd_sample_affine generates noise on the device; for host noise drive dd_forward + dd_affine_step");
     if (a->late) {
@@ -1203,7 +1204,7 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
     }
     DD_HIP(c, hipStreamSynchronize(s));            // a previous call's upload may still read the host staging copy
     c->atab_host.assign((size_t)n + 1, AffineRow{0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0});
-    for (int k = 0; k < n; ++k) c->atab_host[k] = AffineRow{a->t[k], a->a[k], a->b[k], a->c[k], a->noise[k] ? 1 : 0, 0, 0, 0};
+    for (int k = 0; k < n; ++k) c->atab_host[k] = AffineRow{a->t[k], a->a[k], a->b[k], a->c[k], a->noise[k] ? 1 : 0, a->counter_base + k, 0, 0};
     DD_HIP(c, hipMemcpyAsync(c->atab, c->atab_host.data(), ((size_t)n + 1) * sizeof(AffineRow), hipMemcpyHostToDevice, s));
 
     float* x_run = a->x_dev;

@@ -50,7 +50,7 @@ struct StepCoef {
 // one step of a table-driven loop (dd_sample_affine): x' = a x + b eps + c z, the model sees t_model
 struct AffineRow {
     float t_model, a, b, c;
-    int noise, pad0, pad1, pad2;
+    int noise, ctr, pad1, pad2;   // ctr: the Philox counter of this step's z (the step's index in the WHOLE loop, not in this call's table)
 };
 
 enum GemmEpilogue {

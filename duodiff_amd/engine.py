@@ -275,9 +275,11 @@ def sample_loop(ctx: Context, first: Model, late, x, *, t_switch=0, t_start=999,
 
 
 def sample_affine_loop(ctx: Context, first: Model, late, x, t, a, b, c, noise_flags, *, switch_after=None, y=None, seed=0,
-                       noise="philox", use_graph=True, stream=None):
+                       counter_base=0, noise="philox", use_graph=True, stream=None):
     """dd_sample_affine: the table-driven loops (DDIM, predict_original / predict_previous) on the device, in place on x:
-    x <- a[k] x + b[k] model(x, t[k]) + c[k] z for k = 0 .. len(t) - 1; the late model runs from step switch_after on."""
+    x <- a[k] x + b[k] model(x, t[k]) + c[k] z for k = 0 .. len(t) - 1; the late model runs from step switch_after on.
+    Step k draws z from Philox(key = seed, counter = counter_base + k): a loop cut into several calls passes the number
+    of steps already done as counter_base and draws exactly the z of the uncut loop."""
     n = len(t)
     f32 = lambda v: np.ascontiguousarray(v, np.float32)
     tt, aa, bb, cc = f32(t), f32(a), f32(b), f32(c)
@@ -294,6 +296,7 @@ def sample_affine_loop(ctx: Context, first: Model, late, x, t, a, b, c, noise_fl
     args.noise_mode = {"none": L.DD_NOISE_NONE, "philox": L.DD_NOISE_PHILOX}[noise]
     args.use_graph = int(bool(use_graph))
     args.seed = int(seed)
+    args.counter_base = int(counter_base)
     args.y_dev = y.data_ptr() if y is not None else None
     args.x_dev = x.data_ptr()
     args.B = x.shape[0]

@@ -153,7 +153,8 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
 
     def affine_segments(steps, switch_after):
         """noise == "device": the table-driven loop on the device (dd_sample_affine: one hipGraph replay per step, Philox z),
-        cut at the save points.  steps: [(t, a, b, c, draws_noise, saves_after)]."""
+        cut at the save points.  steps: [(t, a, b, c, draws_noise, saves_after)].  Every segment keeps the seed and passes its
+        first step's index as the Philox counter base: the final samples do not depend on where the loop is cut."""
         k0 = 0
         while k0 < len(steps):
             k1 = next((k + 1 for k in range(k0, len(steps)) if steps[k][5]), len(steps))
@@ -162,7 +163,7 @@ def get_samples(model, batch_size: int, postprocessing: callable, seed: int, num
             seg_first, seg_late = (first, late) if (sw is None or sw > 0) else (late, None)
             sample_affine_loop(ctx, seg_first, seg_late if sw is not None and 0 < sw < len(seg) else None, x,
                                [v[0] for v in seg], [v[1] for v in seg], [v[2] for v in seg], [v[3] for v in seg],
-                               [int(v[4]) for v in seg], switch_after=sw, y=y, seed=seed + k0, noise="philox", use_graph=use_graph)
+                               [int(v[4]) for v in seg], switch_after=sw, y=y, seed=seed, counter_base=k0, noise="philox", use_graph=use_graph)
             if seg[-1][5]:
                 intermediate.append(x.clone())
             k0 = k1

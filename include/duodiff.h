@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 2
+#define DD_ABI_VERSION 3
 
 typedef struct dd_ctx dd_ctx;
 typedef struct dd_model dd_model;
@@ -210,7 +210,8 @@ typedef struct dd_affine_sample_args {
     const int64_t* y_dev;   /* [B] or NULL                                                                      */
     float* x_dev;           /* in / out, [B,C,S,S] fp32                                                         */
     int32_t B;
-    int32_t reserved;
+    int32_t counter_base;   /* Philox counter of step 0 of THIS call: step k draws z with counter counter_base + k and key seed, so a loop cut
+                             * into several calls (intermediate saves) with counter_base = steps already done draws the z of one uncut call   */
 } dd_affine_sample_args;
 int dd_sample_affine(dd_ctx* ctx, const dd_affine_sample_args* args, void* stream);
 

@@ -25,16 +25,21 @@ STEP_TOL = 1e-3
 
 
 def eps_tol(precision, ref, full_size=False):
-    """max-abs bound on eps: absolute in the exact-fp32 mode, relative to the spread of the reference output in bf16 mode.
-
-    bf16: 3e-2 sigma for the tiny fixtures.  The full-size (13-block) cases sit at 2.75e-2 .. 3.2e-2 sigma: the max over a
-    1536-value slice moves by +-5% with every change of accumulation order in a kernel (measured over the round-2 and round-3
-    builds: 8.4e-3 .. 9.6e-3 for uvit_cifar10, sigma 0.30), so their max bound is 3.5e-2 sigma and the stable statistic, the rms
-    error (EPS_RMS_TOL), carries the tight bound."""
-    return 1e-4 if precision == "fp32" else (3.5e-2 if full_size else 3e-2) * float(np.asarray(ref, np.float64).std())
+    """max-abs bound on eps: absolute in the exact-fp32 mode; in bf16 mode a LOOSE guard relative to the spread of the reference
+    output -- 3e-2 sigma for the tiny fixtures, 5e-2 sigma for the full-size cases (observed 1.4 .. 3.4e-2 sigma: the maximum of a
+    1536-value slice moves by +-5 % with every change of accumulation order in a kernel, so it is not the regression gate).
+    The gate is the rms error, per config: EPS_RMS_OBSERVED x 1.25."""
+    return 1e-4 if precision == "fp32" else (5e-2 if full_size else 3e-2) * float(np.asarray(ref, np.float64).std())
 
 
-EPS_RMS_TOL = 1e-2     # bf16, full-size cases: rms(eps - ref) <= 1e-2 sigma (measured 6e-3 .. 7e-3)
+# bf16 engine vs the reference, full-size configs, B = 2: rms(eps - ref) / sigma(ref) as measured on MI355X (profiles/r04/parity_numbers.txt;
+# an error model for scale: every block rounds ~6 GEMM operands to bf16, relative rms 2^-9 / sqrt(3) each, adding in quadrature over
+# the depth: 1.1e-3 sqrt(6 depth) = 4.8e-3 (depth 3) .. 1.2e-2 (depth 21)).  The test allows observed x 1.25.
+EPS_RMS_OBSERVED = {
+    "uvit_cifar10": 9.2e-3, "uvit_cifar10_3": 4.6e-3, "uvit_celeba": 5.6e-3, "uvit_celeba_3": 5.1e-3,
+    "uvit_imagenet64": 6.9e-3, "uvit_imagenet64_3": 5.5e-3, "uvit_imagenet256": 5.3e-3, "uvit_imagenet256_3": 4.8e-3,
+}
+EPS_RMS_MARGIN = 1.25
 
 
 def _uvit(cfg, seed, precision, max_batch=None):
@@ -53,7 +58,7 @@ def _oracle(cfg, seed):
 def test_library_loaded_in_tree():
     from duodiff_amd import _lib
     lib = _lib.load()
-    assert str(_lib.LIB_PATH).endswith("duodiff_amd/libduodiff.so") and lib.dd_abi_version() == 2
+    assert str(_lib.LIB_PATH).endswith("duodiff_amd/libduodiff.so") and lib.dd_abi_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -86,7 +91,7 @@ def test_forward_full_size_vs_reference(golden, name, precision):
     print(f"{name} {precision}: max|eps - ref| (slice) = {err:.3e}, rms {rms:.3e} ({rms / sigma:.2e} sigma); std {eps.std():.4f} vs {st[1]:.4f}")
     assert err <= eps_tol(precision, fx["eps_slice"], full_size=True)
     if precision == "bf16":
-        assert rms <= EPS_RMS_TOL * sigma
+        assert rms <= EPS_RMS_MARGIN * EPS_RMS_OBSERVED[name] * sigma, f"rms {rms / sigma:.3e} sigma vs observed {EPS_RMS_OBSERVED[name]:.1e} x {EPS_RMS_MARGIN}"
     assert abs(eps.std(dtype=np.float64) - st[1]) <= (1e-4 if precision == "fp32" else 5e-3)
     assert abs(eps.astype(np.float64).sum() - float(fx["checksum"])) <= (1e-5 if precision == "fp32" else 2e-3) * eps.size
 
@@ -270,32 +275,36 @@ DRIFT_BOUND = {1: (2.9e-4, 5.5e-5), 10: (1.8e-3, 3.4e-4), 100: (6.1e-3, 1.2e-3)}
 
 
 @pytest.mark.parametrize("B,qkv_bias", [(8, False), (3, True)])
-def test_class_conditional_width_512_bf16_vs_fp32_engine(B, qkv_bias):
+def test_class_conditional_width_512_vs_oracle(B, qkv_bias):
     """No shipped config is class-conditional at embed_dim 512, so nothing full-size puts TWO extra tokens (label + time,
     L = 258) through the launches the headline path is made of: the attention launch that computes attn.qkv itself (extra
     tokens as keys, as the split query chunk, their norm1 + qkv inside), the fused block tail with 2 B extra-token rows
     (hidden-split tiles, reduce, column-split skip_linear rows), the fragment-order LayerNorm of the first block.  A synthetic
-    5-block model of that shape, bf16 engine against the fp32 engine (the GEMM sequence, pinned to the reference by the
-    other tests); B = 8 takes the XCD-grouped workgroup map, B = 3 the plain one; with and without qkv bias."""
+    5-block model of that shape: BOTH engines against the numpy oracle (reference models/uvit.py:351-383 restated; pinned to the
+    reference by tests/test_oracle_golden.py) -- the fp32 engine runs gemm256 + attention_kernel at this shape, which no
+    fixture covers either.  B = 8 takes the XCD-grouped workgroup map, B = 3 the plain one; with and without qkv bias."""
     cfg = dict(img_size=32, patch_size=2, in_chans=3, embed_dim=512, depth=5, num_heads=8, mlp_ratio=4, qkv_bias=qkv_bias,
                mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
     g = torch.Generator().manual_seed(77 + B)
     x = torch.randn(B, 3, 32, 32, generator=g)
     y = torch.randint(0, 10, (B,), generator=g)
     t = torch.full((B,), 417.0)
-    mb, _ = _uvit(cfg, 4242, "bf16", max_batch=B)
-    eb = mb(x, t, y).cpu().numpy()
-    del mb
-    mf, _ = _uvit(cfg, 4242, "fp32", max_batch=B)
-    ef = mf(x, t, y).cpu().numpy()
-    assert np.isfinite(eb).all() and np.isfinite(ef).all()
-    sigma = float(ef.std())
-    err, rms = float(np.abs(eb - ef).max()), float(np.sqrt(((eb - ef).astype(np.float64) ** 2).mean()))
-    print(f"class-conditional D=512 L=258 B={B} qkv_bias={qkv_bias}: bf16 vs fp32 engine max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
-    # The maximum is over the whole output (25 k / 9 k values, not a 1.5 k-value slice), and this synthetic model's output is small
-    # (sigma 0.28): its ABSOLUTE rms error, 3.0e-3, equals that of its unconditional twin (3.1e-3 at sigma 0.42 = 7e-3 sigma), so the
-    # bounds relative to sigma are 5e-2 / 1.3e-2 here (measured 4.1e-2 / 1.06e-2)
-    assert err <= 5e-2 * sigma and rms <= 1.3e-2 * sigma
+    want = _oracle(cfg, 4242)(x.numpy(), t.numpy(), y.numpy())
+    sigma = float(want.std())
+    for prec in ("fp32", "bf16"):
+        m, _ = _uvit(cfg, 4242, prec, max_batch=B)
+        got = m(x, t, y).cpu().numpy()
+        del m
+        assert np.isfinite(got).all()
+        err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
+        print(f"class-conditional D=512 L=258 B={B} qkv_bias={qkv_bias} {prec}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+        if prec == "fp32":
+            assert err <= 1e-4
+        else:
+            # The maximum is over the whole output (25 k / 9 k values, not a 1.5 k-value slice), and this synthetic model's output is
+            # small (sigma 0.28): its ABSOLUTE rms error, 3.0e-3, equals that of its unconditional twin (3.1e-3 at sigma 0.42 = 7e-3
+            # sigma).  Observed (round 3, against the fp32 engine): max 4.1e-2 sigma, rms 1.06e-2 sigma; gate = rms x 1.25, max = loose guard
+            assert rms <= 1.25 * 1.06e-2 * sigma and err <= 6e-2 * sigma
 
 
 @pytest.mark.parametrize("K", [1, 10, 100])
@@ -415,6 +424,87 @@ def test_device_resident_ddim_and_parametrization_loops(precision):
     g0, _ = run(use_ddim=True, ddim_steps=50, ddim_eta=0.0, t_switch=300, noise="device")
     g1, _ = run(use_ddim=True, ddim_steps=50, ddim_eta=0.01, t_switch=300, noise="device")
     assert not np.array_equal(g0, g1)
+
+
+def test_save_points_do_not_change_the_final_samples():
+    """Cutting a device-resident loop at intermediate save points (timesteps_save) must not change the final samples: every
+    segment keeps the seed and continues the Philox counter at its first step's index (dd_affine_sample_args.counter_base),
+    so step k draws the same z whether or not the loop was cut before it.  Noisy DDIM (eta > 0), predict_original and
+    predict_previous with a backbone switch; and the DDPM loop (dd_sample: counter = t) for completeness."""
+    from duodiff_amd import sampler
+    m_s, _ = _uvit(dict(TINY, depth=1), 300, "fp32")
+    m_f, _ = _uvit(dict(TINY, depth=3), 301, "fp32")
+    run = lambda **kw: sampler.get_samples(m_s, 3, kw.pop("post", sampler.predict_noise_postprocessing), 7, 3, 8, 8,
+                                           late_model=m_f, noise="device", **kw)
+    for kw, saves in ((dict(use_ddim=True, ddim_steps=40, ddim_eta=0.02, t_switch=400), [1, 300, 640]),
+                      (dict(post=sampler.predict_original_postprocessing, num_steps=50, t_switch=975), [2, 30]),
+                      (dict(post=sampler.predict_previous_postprocessing, num_steps=40, t_switch=980), [5, 6, 39]),
+                      (dict(num_steps=60, t_switch=30), [10, 45])):
+        plain, _ = run(**dict(kw))
+        cut, inter = run(timesteps_save=saves, **dict(kw))
+        assert np.isfinite(plain).all() and len(inter) >= 2
+        assert np.array_equal(plain, cut), f"{kw}: final samples depend on the save points"
+        assert not np.array_equal(inter[0], inter[-1])
+    # and the noise is really there: another seed gives other samples
+    a, _ = run(use_ddim=True, ddim_steps=40, ddim_eta=0.02, t_switch=400)
+    b, _ = sampler.get_samples(m_s, 3, sampler.predict_noise_postprocessing, 8, 3, 8, 8, late_model=m_f, noise="device",
+                               use_ddim=True, ddim_steps=40, ddim_eta=0.02, t_switch=400)
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("num_classes", [-1, 10])
+@pytest.mark.parametrize("D,H", [(128, 2), (256, 4)])
+def test_fused_branches_at_small_widths_vs_oracle(D, H, num_classes):
+    """embed_dim 128 / 256 take launches no shipped config reaches through a model: the fused block tail with the NEXT block's
+    attn.qkv inside it (QKV instantiation, ragged tiles: qkv_dump), launch_qkv_rows on the extra-token rows, the bf16
+    head-major qkv GEMM of the first block, attention_kernel on that tensor.  7-block models (3 in / mid / 3 out: skip_linear
+    phases too), 64 patches + 1 or 2 extra tokens, B = 5 (ragged 128-row tile), both precisions against the numpy oracle."""
+    cfg = dict(img_size=16, patch_size=2, in_chans=3, embed_dim=D, depth=7, num_heads=H, mlp_ratio=4, qkv_bias=False,
+               mlp_time_embed=False, num_classes=num_classes, normalize_timesteps=True)
+    B = 5
+    g = torch.Generator().manual_seed(D + B)
+    x = torch.randn(B, 3, 16, 16, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g) if num_classes > 0 else None
+    t = torch.full((B,), 250.0)
+    want = _oracle(cfg, 99)(x.numpy(), t.numpy(), y.numpy() if y is not None else None)
+    sigma = float(want.std())
+    for prec in ("fp32", "bf16"):
+        m, _ = _uvit(cfg, 99, prec, max_batch=B)
+        got = m(x, t, y).cpu().numpy()
+        del m
+        err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
+        print(f"D={D} classes={num_classes} {prec}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+        assert np.isfinite(got).all()
+        assert err <= (1e-4 if prec == "fp32" else 6e-2 * sigma) and (prec == "fp32" or rms <= 1.5e-2 * sigma)
+
+
+@pytest.mark.parametrize("flags", [32, 64, 128, 32 | 128, 64 | 128, 1, 2, 4])
+def test_kernel_variant_flags_agree_with_the_default_path(flags):
+    """Every dd_dev_set_flags setting selects another launch sequence for the same arithmetic (run_backbone's h_ready /
+    skip_done / qkv_done / qa_ready state machine): on a 5-block class-conditional model at embed_dim 512 each variant must
+    stay within bf16 rounding of the oracle, like the default path (32 = no fused skip_linear, 64 = no qkv in the block tail,
+    128 = no qkv inside the attention launch -> the QKV instantiation / the qkv GEMM, and their combinations)."""
+    from duodiff_amd.engine import Context
+    cfg = dict(img_size=32, patch_size=2, in_chans=3, embed_dim=512, depth=5, num_heads=8, mlp_ratio=4, qkv_bias=False,
+               mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
+    B = 3
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    t = torch.full((B,), 600.0)
+    want = _oracle(cfg, 4243)(x.numpy(), t.numpy(), y.numpy())
+    sigma = float(want.std())
+    ctx = Context.get()
+    try:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+        m, _ = _uvit(cfg, 4243, "bf16", max_batch=B)
+        got = m(x, t, y).cpu().numpy()
+        del m
+    finally:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+    err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
+    print(f"dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+    assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
 
 
 def test_cli_end_to_end(tmp_path):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared | dev_declared == set(_lib.SIGNATURES), (declared | dev_declared) ^ set(_lib.SIGNATURES)
     for name in declared | dev_declared:
         assert hasattr(lib, name), name
-    assert lib.dd_abi_version() == 2
+    assert lib.dd_abi_version() == _lib.ABI_VERSION
 
 
 def test_engine_schedule_tables_bit_exact_with_reference(golden):

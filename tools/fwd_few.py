@@ -1,16 +1,22 @@
-"""Dev tool for rocprofv3: a few full-model forwards at the headline shapes (CelebA, B=128, bf16)."""
+"""Dev tool for rocprofv3: a few full-model forwards of one BASELINE workload's full backbone (bf16, its BASELINE batch).
+
+    python tools/fwd_few.py [celeba|imagenet64|imagenet256]
+"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from duodiff_amd.config import ModelParams, load_config
 from duodiff_amd.uvit import UViT
 from duodiff_amd.weights import synthetic_state_dict
-cfg = load_config("/root/repo/configs/uvit_celeba.yaml")
+W = {"celeba": ("uvit_celeba", 128), "imagenet64": ("uvit_imagenet64", 256), "imagenet256": ("uvit_imagenet256", 32)}
+name, B = W[sys.argv[1] if len(sys.argv) > 1 else "celeba"]
+cfg = load_config(f"/root/repo/configs/{name}.yaml")
 mp = ModelParams.from_dict(cfg)
-m = UViT(**mp.as_dict(), precision="bf16", max_batch=128)
+m = UViT(**mp.as_dict(), precision="bf16", max_batch=B)
 m.load_state_dict(synthetic_state_dict(mp, 1))
 m.to("cuda")
-x = torch.randn(128, 3, 64, 64)
+x = torch.randn(B, mp.in_chans, mp.img_size, mp.img_size)
+y = torch.randint(1, 1001, (B,)).clamp(max=mp.num_classes - 1) if mp.num_classes > 0 else None
 for _ in range(3):
-    e = m(x, torch.full((128,), 500.0))
+    e = m(x, torch.full((B,), 500.0), y)
 torch.cuda.synchronize()
 print("ok", float(e.abs().mean()))

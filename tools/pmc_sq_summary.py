@@ -1,16 +1,18 @@
-"""Per-kernel SQ utilisation from one rocprofv3 --pmc pass
-(SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
- SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS).
+"""Per-kernel SQ utilisation and the clock under load from one rocprofv3 --pmc pass
+(SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
+ SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE).
 
     python tools/pmc_sq_summary.py <rocprofv3 output dir> [out.json] > table.txt
 
-mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs * kernel cycles), kernel cycles from the launch duration at the clock
-the counters imply (SQ_BUSY_CYCLES is per-SE; we use wave lifetime instead): per launch,
-    wave_clk  = SQ_WAVE_CYCLES * 4 / SQ_WAVES      (mean lifetime of a wave in clocks; the counter ticks per 4 clocks)
-    mfma_clk  = SQ_VALU_MFMA_BUSY_CYCLES / 1024    (MFMA-pipe busy clocks per SIMD; 256 CUs x 4 SIMDs)
-    mfma_busy = mfma_clk / (wave_clk * rounds)     rounds = waves per SIMD slot actually used = SQ_WAVES / (1024 * waves resident per SIMD)
-For the one-wave-per-SIMD kernels (fused MLP: 1028+ waves on 1024 SIMDs) the denominator is the kernel's own duration in
-clocks, which is what the table prints as `mfma/dur` using the measured duration and the clock implied by wave_clk.
+Per launch (means over the upper half of a kernel's launches by value = the full-size ones):
+    mfma_clk      = SQ_VALU_MFMA_BUSY_CYCLES / (CUs x 4)    MFMA-pipe busy clocks per SIMD (the counter is in clocks: 32 per 32x32x16 bf16 MFMA)
+    gui_clk       = GRBM_GUI_ACTIVE / 8                       clocks the chip was busy for this dispatch (rocprofv3 sums the 8 XCDs)
+    sclk_mhz      = gui_clk / duration                        the clock the part held under this kernel (MI355X_MICROARCH.md, DVFS give-back:
+                                                              reads up to a few % high on dispatches shorter than 0.3 ms, and profiled passes run
+                                                              2-5 % slower than un-profiled ones)
+    mfma_busy_launch = mfma_clk / gui_clk                     LAUNCH-level utilisation of the matrix pipe: busy clocks / clocks of the launch
+    mfma_busy_wave   = mfma_clk / mean wave lifetime          (the round-3 figure: per resident wave, not per launch -- it exceeds the launch-level
+                                                              one whenever short-lived waves pull the mean lifetime down; > 1 with 2 waves per SIMD)
 """
 import collections
 import csv
@@ -21,6 +23,7 @@ import re
 import sys
 
 d = sys.argv[1]
+NSIMD = 256 * 4
 clean = lambda n: re.sub(r"dd::|\(anonymous namespace\)::|unsigned short", "", n)
 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -43,23 +46,29 @@ def upper_mean(v):       # the full-size launches: upper half by value
 
 
 out = {}
-print(f"{'kernel':60s} {'waves':>7s} {'wave_clk':>9s} {'mfma_clk':>9s} {'mfma/wave':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'lds_conf':>8s} {'us(pmc)':>8s}")
+print(f"{'kernel':60s} {'waves':>7s} {'us(pmc)':>8s} {'sclk MHz':>8s} {'mfma_clk':>9s} {'busy/launch':>11s} {'busy/wave':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'lds_conf':>8s}")
 for k, c in sorted(acc.items(), key=lambda kv: -upper_mean(kv[1].get("SQ_WAVE_CYCLES", [0]))):
     if "SQ_WAVES" not in c:
         continue
     g = lambda n: upper_mean(c[n]) if n in c else float("nan")
     waves, wc = g("SQ_WAVES"), g("SQ_WAVE_CYCLES")
     wave_clk = wc * 4 / max(waves, 1)
-    mfma_clk = g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024
-    row = dict(waves=waves, wave_clk=wave_clk, mfma_clk_per_simd=mfma_clk, mfma_busy_frac=mfma_clk / wave_clk if wave_clk else 0.0,
+    mfma_clk = g("SQ_VALU_MFMA_BUSY_CYCLES") / NSIMD
+    us = upper_mean(dur[k]) / 1e3 if dur[k] else None
+    gui_clk = g("GRBM_GUI_ACTIVE") / 8 if "GRBM_GUI_ACTIVE" in c else None
+    row = dict(waves=waves, wave_clk=wave_clk, mfma_clk_per_simd=mfma_clk,
+               mfma_busy_frac_launch=(mfma_clk / gui_clk) if gui_clk else None,
+               sclk_mhz_under_load=(gui_clk / us) if (gui_clk and us) else None, gui_active_clk=gui_clk,
+               mfma_busy_frac_wave_lifetime=mfma_clk / wave_clk if wave_clk else 0.0,
                wait_any=g("SQ_WAIT_ANY") / wc if wc else 0.0, wait_inst=g("SQ_WAIT_INST_ANY") / wc if wc else 0.0,
                active=g("SQ_ACTIVE_INST_ANY") / wc if wc else 0.0,
                lds_conflict_per_lds_active=(g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS")) if c.get("SQ_ACTIVE_INST_LDS") and g("SQ_ACTIVE_INST_LDS") else None,
-               avg_us_under_pmc=(upper_mean(dur[k]) / 1e3 if dur[k] else None))
+               avg_us_under_pmc=us)
     out[k] = row
     lc = row["lds_conflict_per_lds_active"]
-    print(f"{k[:60]:60s} {waves:7.0f} {wave_clk:9.0f} {mfma_clk:9.0f} {row['mfma_busy_frac']:9.2f} {row['wait_any']:8.2f} {row['wait_inst']:9.2f} "
-          f"{row['active']:7.2f} {(lc if lc is not None else float('nan')):8.3f} {(row['avg_us_under_pmc'] or 0):8.1f}")
+    nan = float("nan")
+    print(f"{k[:60]:60s} {waves:7.0f} {(us or 0):8.1f} {(row['sclk_mhz_under_load'] or nan):8.0f} {mfma_clk:9.0f} {(row['mfma_busy_frac_launch'] if row['mfma_busy_frac_launch'] is not None else nan):11.3f} "
+          f"{row['mfma_busy_frac_wave_lifetime']:9.2f} {row['wait_any']:8.2f} {row['wait_inst']:9.2f} {row['active']:7.2f} {(lc if lc is not None else nan):8.3f}")
 if len(sys.argv) > 2:
     # the build the counters were collected on (bench.py quotes them only for that build)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
