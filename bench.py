@@ -311,6 +311,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing = ctx.last_sample_timing()   # hipEvents around the K steps of this rank's dd_sample call
+    chains = int(ctx.lib.dd_dev_last_sample_chains(ctx.handle))   # 2: the batch ran as two half-batch chains on two streams
     on_dev = dist is None or dist.get_backend() == "nccl"
     gather_ms = ev_g0.elapsed_time(ev_g1) if (dist is not None and dist.get_backend() == "nccl") else 0.0
     # MAX over ranks of (wall, GPU ms of the K steps, all_gather ms, -GPU ms): the last entry gives the MIN, so that a slow or
@@ -372,6 +373,10 @@ def main():
             "config": {"workload": "%s DuoDiff: %s (t=999..700) + %s (t=699..0), t_switch=300, 1000-step DDPM, batch %d/GPU, "
                                    "device Philox noise" % (label, cfg_s, cfg_f, B),
                        "batch_per_gpu": B, "t_switch": a.t_switch, "hipgraph": use_graph,
+                       # dd_sample runs an even batch >= 32 as two independent half-batch chains on two streams (bit-identical results:
+                       # one chain's HBM-bound phases overlap the other's MFMA phases); the roofline leg below times the kernel ALONE
+                       # on the chip at the full batch, one chain
+                       "chains_in_timed_region": chains,
                        "timed_steps": K, "switch_after_steps": k_switch,
                        "seconds_per_sample": (dt * 1000.0 / K) / images, "finite": finite,
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],

@@ -15,6 +15,7 @@ DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, D
 ABI_VERSION = 3
 DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_EMBED, DD_DEV_MLP_EXTRAS_ONLY = 1, 2, 4, 8, 16
 DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV, DD_DEV_NO_FUSED_QA = 32, 64, 128
+DD_DEV_NO_CHAINS, DD_DEV_FORCE_CHAINS = 256, 512
 
 
 class dd_config(C.Structure):
@@ -88,6 +89,7 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),
     "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
+    "dd_dev_last_sample_chains": (C.c_int, [C.c_void_p]),
     "dd_dev_set_flags": (C.c_int, [C.c_void_p, C.c_uint]),
     "dd_set_num_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "dd_plan_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -32,6 +32,9 @@ struct dd_ctx {
     int device = 0;
     std::string err;
     StepState* st = nullptr;     // device
+    StepState* st2 = nullptr;    // device: the second half-batch chain of dd_sample (its own timestep / counter)
+    hipStream_t side = nullptr;  // that chain's stream (context-owned, non-blocking)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     StepCoef* coef = nullptr;    // device [1000]
     StepCoef coef_host[1000];
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -43,6 +46,7 @@ struct dd_ctx {
     int64_t* y_stage = nullptr;
     size_t x_stage_elems = 0, y_stage_elems = 0;
     long long graph_captures = 0;
+    int last_chains = 1;         // chains the last dd_sample call ran (dd_dev_last_sample_chains)
     // dd_sample_affine: the step table on the device (+ its host staging copy, which must outlive the async upload)
     AffineRow* atab = nullptr;
     size_t atab_rows = 0;
@@ -73,13 +77,23 @@ struct GraphKey {
     const void* atab;                                                // dd_sample_affine's table (null: the DDPM update)
     const void *aux0 = nullptr, *aux1 = nullptr;                     // dd_sample_early_exit: the two log tables
     float thr = 0.f;                                                 //                        and the threshold
+    int b0 = 0;                                                      // first image of a half-batch chain within the whole batch
     bool operator==(const GraphKey& o) const {
         return x == o.x && y == o.y && B == o.B && noise == o.noise && variance == o.variance && num_cus == o.num_cus &&
-               atab == o.atab && aux0 == o.aux0 && aux1 == o.aux1 && thr == o.thr;
+               atab == o.atab && aux0 == o.aux0 && aux1 == o.aux1 && thr == o.thr && b0 == o.b0;
     }
 };
 
 }  // namespace
+
+// The activation workspace of one chain: dd_sample runs a large batch as TWO independent half-batch chains on two streams (one
+// chain's HBM-bound kernel phases then run under the other's MFMA phases); the second chain has its own copy of every buffer.
+struct WsPtrs {
+    float* x = nullptr; void *h = nullptr, *ao = nullptr, *qkv = nullptr, *hid = nullptr, *xb = nullptr;
+    std::vector<void*> skips;
+    float* dec = nullptr; float* mlp_partial = nullptr; bf16_t* qkv_dump = nullptr; bf16_t* hfrag = nullptr;
+};
+struct WsOffsets { size_t x, h, ao, qkv, hid, xb, dec, part, dump, hf, bytes; std::vector<size_t> sk; bool has_part, has_dump, has_hf; };
 
 struct dd_model {
     dd_ctx* ctx = nullptr;
@@ -115,8 +129,11 @@ struct dd_model {
     bf16_t* hfrag = nullptr;              // fused_qa: norm1 of the patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
-    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
-    GraphKey gkey[3]{};                                      // [2] early-exit step (dd_sample_early_exit)
+    hipGraphExec_t graph[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
+    GraphKey gkey[4]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] DDPM step of the second chain
+    WsOffsets wsoff{};
+    char* wsarena2 = nullptr;                                // the second chain's workspace (allocated by the first chained dd_sample)
+    WsPtrs ws2;
     float* ee_ws = nullptr;                                  // dd_sample_early_exit scratch: eps | model_output | cls | outs
     size_t ee_ws_elems = 0;
     // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
@@ -377,6 +394,24 @@ std::vector<std::string> required_names(const dd_model* m) {
     return v;
 }
 
+void bind_ws(const WsOffsets& o, char* arena, WsPtrs& w) {
+    w.x = (float*)(arena + o.x); w.h = arena + o.h; w.ao = arena + o.ao; w.qkv = arena + o.qkv; w.hid = arena + o.hid; w.xb = arena + o.xb;
+    w.dec = (float*)(arena + o.dec);
+    w.skips.clear();
+    for (size_t v : o.sk) w.skips.push_back(arena + v);
+    w.mlp_partial = o.has_part ? (float*)(arena + o.part) : nullptr;
+    w.qkv_dump = o.has_dump ? (bf16_t*)(arena + o.dump) : nullptr;
+    w.hfrag = o.has_hf ? (bf16_t*)(arena + o.hf) : nullptr;
+}
+// exchange the model's workspace pointers with the second chain's (the caller swaps the context's step state too): the launch sequence of a step is
+// enqueued / captured for that chain by the same code, on the same weights
+void swap_chain(dd_model* m) {
+    WsPtrs& w = m->ws2;
+    std::swap(m->x, w.x); std::swap(m->h, w.h); std::swap(m->ao, w.ao); std::swap(m->qkv, w.qkv); std::swap(m->hid, w.hid);
+    std::swap(m->xb, w.xb); std::swap(m->dec, w.dec); std::swap(m->skips, w.skips); std::swap(m->mlp_partial, w.mlp_partial);
+    std::swap(m->qkv_dump, w.qkv_dump); std::swap(m->hfrag, w.hfrag);
+}
+
 // ---- the forward: tokens -> blocks -> decoder_pred patches (m->dec) ---------------------------
 // early-exit taps of one forward (EarlyExitUViT.forward, early_exit.py:290-313): cls [depth, B], outs [depth, B, C, S, S]
 struct EeTaps { float* cls; float* outs; int t; };
@@ -580,11 +615,11 @@ int check_call(dd_ctx* c, dd_model* m, int B, const int64_t* y_dev) {
 // one sampling step enqueued on s: x <- update(x, model(x, t)) ; t comes from ctx->st
 // advance != 0: the step's last kernel also decrements the device-resident timestep (graph replays / dd_sample)
 int enqueue_step(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int noise_mode, const float* z_dev,
-                 int variance, float* eps_out, int B, hipStream_t s, int advance = 0, const AffineRow* atab = nullptr) {
+                 int variance, float* eps_out, int B, hipStream_t s, int advance = 0, const AffineRow* atab = nullptr, int b0 = 0) {
     int rc = run_model(m, x_dev, nullptr, y_dev, B, s);
     if (rc) return rc;
     FinalArgs fa{m->dec, m->wconv, m->bconv, x_dev, z_dev, eps_out, x_dev, c->st, c->coef,
-                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance, advance, atab};
+                 B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, noise_mode, variance, advance, atab, b0};
     DD_HIP(c, launch_final(fa, s));
     return DD_OK;
 }
@@ -609,6 +644,25 @@ int stage_inputs(dd_ctx* c, const float* x_dev, const int64_t* y_dev, int B, siz
     if (y_dev) DD_HIP(c, hipMemcpyAsync(c->y_stage, y_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     *x_run = c->x_stage;
     *y_run = y_dev ? c->y_stage : nullptr;
+    return DD_OK;
+}
+
+// dd_sample splits an even batch of at least 32 images into two half-batch chains where that pays (same-box A/B, profiles/r04/
+// ab_chains.txt): the fused-path models (their kernels have strong MFMA / HBM phase structure and one tile per CU at the benchmark batch:
+// CelebA B = 128 +10.5 %), and GEMM-path models whose launches leave CUs idle (ImageNet-256 latents, B = 32: +7.7 %); NOT the GEMM
+// path at large batches (ImageNet-64, B = 256: its persistent grids fill every CU's LDS, two chains only queue behind each other:
+// -4.7 %).  Development flags force it on for any even batch, or switch it off.
+bool use_chains(dd_ctx* c, dd_model* m, int B) {
+    if ((c->dev_flags & DD_DEV_NO_CHAINS) || (B & 1) || B < 2 || m->ee_type >= 0) return false;
+    if (c->dev_flags & DD_DEV_FORCE_CHAINS) return true;
+    if (B < 32) return false;
+    return (m->prec == DD_PREC_BF16 && m->fused_mlp) || (long long)B * m->L <= 32768;
+}
+int ensure_chain_ws(dd_ctx* c, dd_model* m) {
+    if (m->wsarena2) return DD_OK;
+    DD_HIP(c, hipMalloc((void**)&m->wsarena2, m->wsoff.bytes));
+    DD_HIP(c, hipMemset(m->wsarena2, 0, m->wsoff.bytes));
+    bind_ws(m->wsoff, m->wsarena2, m->ws2);
     return DD_OK;
 }
 
@@ -695,7 +749,11 @@ int dd_ctx_create(int device, dd_ctx** out) {
     for (int i = 0; i < 1000; ++i) c->coef_host[i] = StepCoef{s.c1[i], s.c2[i], s.sigma[i], s.sigma_beta[i]};
     bool ok = hipMalloc(&c->st, sizeof(StepState)) == hipSuccess && hipMalloc(&c->coef, sizeof(StepCoef) * 1000) == hipSuccess &&
               hipMemcpy(c->coef, c->coef_host, sizeof(StepCoef) * 1000, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemset(c->st, 0, sizeof(StepState)) == hipSuccess;
+              hipMemset(c->st, 0, sizeof(StepState)) == hipSuccess && hipMalloc(&c->st2, sizeof(StepState)) == hipSuccess &&
+              hipMemset(c->st2, 0, sizeof(StepState)) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
          init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess;
@@ -707,7 +765,11 @@ int dd_ctx_create(int device, dd_ctx** out) {
 void dd_ctx_destroy(dd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->st) (void)hipFree(c->st);
+    if (c->st2) (void)hipFree(c->st2);
     if (c->coef) (void)hipFree(c->coef);
     if (c->x_stage) (void)hipFree(c->x_stage);
     if (c->y_stage) (void)hipFree(c->y_stage);
@@ -992,15 +1054,16 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
     const size_t o_hf = take(m->fused_qa ? (size_t)m->cfg.max_batch * m->N * D * 2 : 0);
+    m->wsoff = WsOffsets{o_x, o_h, o_ao, o_qkv, o_hid, o_xb, o_dec, o_part, o_dump, o_hf, off, o_sk, part_bytes != 0, m->fused_qkv, m->fused_qa};
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
-    m->x = (float*)(m->wsarena + o_x); m->h = m->wsarena + o_h; m->ao = m->wsarena + o_ao; m->qkv = m->wsarena + o_qkv;
-    m->hid = m->wsarena + o_hid; m->xb = m->wsarena + o_xb; m->dec = (float*)(m->wsarena + o_dec);
-    for (size_t o : o_sk) m->skips.push_back(m->wsarena + o);
-    m->mlp_partial = part_bytes ? (float*)(m->wsarena + o_part) : nullptr;
+    {
+        WsPtrs w;
+        bind_ws(m->wsoff, m->wsarena, w);
+        m->x = w.x; m->h = w.h; m->ao = w.ao; m->qkv = w.qkv; m->hid = w.hid; m->xb = w.xb; m->dec = w.dec; m->skips = w.skips;
+        m->mlp_partial = w.mlp_partial; m->qkv_dump = w.qkv_dump; m->hfrag = w.hfrag;
+    }
     m->mlp_partial_bytes = part_bytes;
-    m->qkv_dump = m->fused_qkv ? (bf16_t*)(m->wsarena + o_dump) : nullptr;
-    m->hfrag = m->fused_qa ? (bf16_t*)(m->wsarena + o_hf) : nullptr;
 
     // host copies are no longer needed
     for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
@@ -1016,6 +1079,7 @@ void dd_model_destroy(dd_model* m) {
     if (m->ee_ws) (void)hipFree(m->ee_ws);
     if (m->warena) (void)hipFree(m->warena);
     if (m->wsarena) (void)hipFree(m->wsarena);
+    if (m->wsarena2) (void)hipFree(m->wsarena2);
     delete m;
 }
 
@@ -1147,21 +1211,49 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     // the loop runs on x_run / y_run: with graphs the context's staging buffers (copied in here, copied back at the end)
     float* x_run = a->x_dev;
     const int64_t* y_run = a->y_dev;
-    const size_t x_elems = (size_t)a->B * a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    const size_t chw = (size_t)a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    const size_t x_elems = (size_t)a->B * chw;
+    // Two half-batch chains (graph replays only).  Images are independent and a row's path through the kernels does not depend on the
+    // batch size, so chain 0 = images [0, B/2) on the caller's stream and chain 1 = images [B/2, B) on the context's side stream
+    // compute bit for bit what the undivided batch computes (Philox pixel ids carry the image offset) -- with the two chains free
+    // to drift apart, so that one's HBM-bound phases (row prologues / epilogues, attention row fetch) run under the other's MFMA phases.
+    const bool chained = a->use_graph && use_chains(c, a->first, a->B) && (!switching || use_chains(c, a->late, a->B));
+    const int B0 = chained ? a->B / 2 : a->B, B1 = a->B - B0;
+    c->last_chains = chained ? 2 : 1;
     if (a->use_graph) {
         if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, x_elems, s, &x_run, &y_run))) return rc;
-        const GraphKey key{x_run, y_run, a->B, a->noise_mode, a->variance, c->num_cus, nullptr};
-        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1); };
+        GraphKey key{x_run, y_run, B0, a->noise_mode, a->variance, c->num_cus, nullptr};
+        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, B0, s, 1); };
         if ((rc = get_graph(c, a->first, 0, key, s, step))) return rc;
         if (switching && (rc = get_graph(c, a->late, 0, key, s, step))) return rc;
+        if (chained) {
+            float* x1 = x_run + (size_t)B0 * chw;
+            const int64_t* y1 = y_run ? y_run + B0 : nullptr;
+            GraphKey key1{x1, y1, B1, a->noise_mode, a->variance, c->num_cus, nullptr};
+            key1.b0 = B0;
+            auto step1 = [&](dd_model* m) {     // the same launch sequence on the second chain's workspace and step state
+                swap_chain(m); std::swap(c->st, c->st2);
+                const int r = enqueue_step(c, m, x1, y1, a->noise_mode, nullptr, a->variance, nullptr, B1, s, 1, nullptr, B0);
+                swap_chain(m); std::swap(c->st, c->st2);
+                return r;
+            };
+            if ((rc = ensure_chain_ws(c, a->first)) || (rc = get_graph(c, a->first, 3, key1, s, step1))) return rc;
+            if (switching && ((rc = ensure_chain_ws(c, a->late)) || (rc = get_graph(c, a->late, 3, key1, s, step1)))) return rc;
+        }
     }
     DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
+    if (chained) {
+        DD_HIP(c, launch_set_state(c->st2, a->t_start, (unsigned long long)a->seed, s));
+        DD_HIP(c, hipEventRecord(c->ev_fork, s));                 // the side stream starts behind the staging copies and the state
+        DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
     DD_HIP(c, hipEventRecord(c->ev[0], s));
     bool marked = false;
     dd_model* cur = a->first;
     for (int t = a->t_start; t >= a->t_end; --t) {
         if (a->use_graph) {
             DD_HIP(c, hipGraphLaunch(cur->graph[0], s));
+            if (chained) DD_HIP(c, hipGraphLaunch(cur->graph[3], c->side));
         } else {
             rc = enqueue_step(c, cur, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, a->B, s, 1);
             if (rc) return rc;
@@ -1171,6 +1263,10 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
             DD_HIP(c, hipEventRecord(c->ev[1], s));
             marked = true;
         }
+    }
+    if (chained) {
+        DD_HIP(c, hipEventRecord(c->ev_join, c->side));
+        DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     }
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));
@@ -1306,6 +1402,7 @@ int dd_sample_early_exit(dd_ctx* c, const dd_ee_sample_args* a, void* stream) {
 }
 
 long long dd_dev_graph_captures(dd_ctx* c) { return c ? c->graph_captures : -1; }
+int dd_dev_last_sample_chains(dd_ctx* c) { return c ? c->last_chains : -1; }
 
 int dd_dev_set_flags(dd_ctx* c, unsigned flags) {
     if (!c) return DD_ERR_INVALID;

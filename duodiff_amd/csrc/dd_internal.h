@@ -207,6 +207,8 @@ struct FinalArgs {
     int advance;
     const AffineRow* atab; // or null.  Set: st->t is a STEP INDEX k into this table; the update is a x + b eps + c z with row k,
                            // and advance hands row k + 1's timestep to the next step (the table holds one row more than steps)
+    int b0 = 0;            // index of this launch's first image within the whole batch (a half-batch chain of dd_sample): only the
+                           // Philox pixel ids depend on it, so that a chain draws the z the undivided batch would
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 

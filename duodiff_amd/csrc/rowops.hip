@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
         if (a.advance && pix == 0) { a.st->t = t + 1; a.st->t_model = a.atab[t + 1].t_model; }
         const bool nz = row.noise != 0 && a.noise_mode == 2;
         f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-        if (a.x_out && nz) zn = philox_normal4(a.st->seed, (unsigned long long)pix, row.ctr);
+        if (a.x_out && nz) zn = philox_normal4(a.st->seed, (unsigned long long)(pix + (long long)a.b0 * S * S), row.ctr);
         for (int co = 0; co < C; ++co) {
             const long long e = (((long long)b * C + co) * S + y) * S + x;
             const float eps = acc[co];
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
     const StepCoef cf = a.coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-    if (a.x_out && t > 0 && a.noise_mode == 2) zn = philox_normal4(a.st->seed, (unsigned long long)pix, t);
+    if (a.x_out && t > 0 && a.noise_mode == 2) zn = philox_normal4(a.st->seed, (unsigned long long)(pix + (long long)a.b0 * S * S), t);
     for (int co = 0; co < C; ++co) {
         const long long e = (((long long)b * C + co) * S + y) * S + x;
         const float eps = acc[co];
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
     }
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
     if (inside && a.x_out && draw && a.noise_mode == 2)
-        zn = philox_normal4(a.st->seed, ((unsigned long long)b * S + y) * S + x, table ? row.ctr : t);   // same pixel id as the untiled kernel
+        zn = philox_normal4(a.st->seed, ((unsigned long long)(b + a.b0) * S + y) * S + x, table ? row.ctr : t);   // same pixel id as the untiled kernel (b0: this launch's first image within the whole batch)
     __syncthreads();
     if (a.advance && blockIdx.x == 0 && tid == 0) {   // no block of this kernel reads t / t_model
         const int tn = table ? t + 1 : t - 1;

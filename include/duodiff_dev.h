@@ -50,11 +50,16 @@ int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const flo
 #define DD_DEV_NO_FUSED_QA 128u     /* keep attn.qkv out of the attention launch (the qkv tensor goes through HBM) */
 #define DD_DEV_GENERIC_EMBED 8u     /* generic VALU patch-embed kernel */
 #define DD_DEV_MLP_EXTRAS_ONLY 16u  /* dd_dev_mlp: launch the hidden-split (extra-token) workgroups alone */
+#define DD_DEV_NO_CHAINS 256u       /* dd_sample: one chain over the whole batch (default: two half-batch chains on two streams for even B >= 32) */
+#define DD_DEV_FORCE_CHAINS 512u    /* dd_sample: two half-batch chains for ANY even batch (tests at small batches) */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
 
 /* Number of hipGraph captures dd_sample has made on this context so far (tests: a second call with other tensors of the
  * same shape must not capture again). */
 long long dd_dev_graph_captures(dd_ctx* ctx);
+
+/* Number of chains the last dd_sample call on this context ran (1, or 2 half-batch chains on two streams). */
+int dd_dev_last_sample_chains(dd_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -189,6 +189,47 @@ def test_switch_and_graph_replay_match_manual_steps():
     assert torch.isfinite(xm).all()
 
 
+@pytest.mark.parametrize("case", ["tiny_forced", "tiny_cond_forced", "celeba_default"])
+def test_half_batch_chains_equal_the_single_chain(case):
+    """dd_sample runs an even batch of >= 32 images as two half-batch chains on two streams (each with its own workspace, step
+    state and captured graphs; images are independent and a row's path through the kernels does not depend on the batch, the Philox
+    pixel ids carry the image offset).  The result must equal the single-chain loop bit for bit: backbone switch inside the run,
+    device noise; tiny models with the split forced at B = 6 (unconditional and class-conditional: the label half moves too),
+    and the CelebA pair at its benchmark batch with the default policy."""
+    from duodiff_amd import _lib as L
+    from duodiff_amd.engine import sample_loop
+    if case == "celeba_default":
+        B, S, C_, steps, tsw, force = 128, 64, 3, 6, 3, 0
+        cfg_s, cfg_f = load_config(REPO / "configs" / "uvit_celeba_3.yaml"), load_config(REPO / "configs" / "uvit_celeba.yaml")
+    else:
+        B, S, C_, steps, tsw, force = 6, 8, 3, 12, 5, L.DD_DEV_FORCE_CHAINS
+        nc = 10 if case == "tiny_cond_forced" else -1
+        cfg_s, cfg_f = dict(TINY, depth=1, num_classes=nc), dict(TINY, depth=3, num_classes=nc)
+    m_s, _ = _uvit(cfg_s, 31, "bf16", max_batch=B)
+    m_f, _ = _uvit(cfg_f, 32, "bf16", max_batch=B)
+    es, ef = m_s.engine_model(B), m_f.engine_model(B)
+    ctx = es.ctx
+    x0 = torch.randn(B, C_, S, S, generator=torch.Generator().manual_seed(4)).cuda()
+    y = torch.randint(0, 10, (B,), generator=torch.Generator().manual_seed(5)).cuda() if case == "tiny_cond_forced" else None
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    outs = {}
+    try:
+        with torch.cuda.stream(stream):
+            for name, flags in (("chained", force), ("single", L.DD_DEV_NO_CHAINS)):
+                ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+                n0 = ctx.lib.dd_dev_graph_captures(ctx.handle)
+                x = x0.clone()
+                sample_loop(ctx, es, ef, x, t_switch=tsw, t_start=999, t_end=1000 - steps, y=y, seed=9, noise="philox", use_graph=True, stream=stream)
+                stream.synchronize()
+                outs[name] = (x.clone(), ctx.lib.dd_dev_graph_captures(ctx.handle) - n0)
+    finally:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+    assert outs["chained"][1] == 4 and outs["single"][1] == 2, f"graph captures: {outs['chained'][1]} chained, {outs['single'][1]} single"
+    assert torch.isfinite(outs["single"][0]).all() and not torch.equal(outs["single"][0], x0)
+    assert torch.equal(outs["chained"][0], outs["single"][0]), "two half-batch chains differ from the single chain"
+
+
 def test_graphs_are_not_recaptured_for_new_tensors():
     """reference get_samples allocates a fresh x per call (sampler.py:98); dd_sample's graphs run on context-owned staging
     buffers, so a second call with other tensors of the same shape replays the captured graphs (and still writes its
@@ -436,7 +477,8 @@ def test_save_points_do_not_change_the_final_samples():
     m_f, _ = _uvit(dict(TINY, depth=3), 301, "fp32")
     run = lambda **kw: sampler.get_samples(m_s, 3, kw.pop("post", sampler.predict_noise_postprocessing), 7, 3, 8, 8,
                                            late_model=m_f, noise="device", **kw)
-    for kw, saves in ((dict(use_ddim=True, ddim_steps=40, ddim_eta=0.02, t_switch=400), [1, 300, 640]),
+    # (DDIM visits t = linspace(0, 999, 40).astype(int) reversed: 1000 - t takes the values 1, 27, ..., 258, ..., 642, ...)
+    for kw, saves in ((dict(use_ddim=True, ddim_steps=40, ddim_eta=0.02, t_switch=400), [1, 258, 642]),
                       (dict(post=sampler.predict_original_postprocessing, num_steps=50, t_switch=975), [2, 30]),
                       (dict(post=sampler.predict_previous_postprocessing, num_steps=40, t_switch=980), [5, 6, 39]),
                       (dict(num_steps=60, t_switch=30), [10, 45])):
