@@ -35,6 +35,7 @@ struct dd_ctx {
     StepState* st2 = nullptr;    // device: the second half-batch chain of dd_sample (its own timestep / counter)
     hipStream_t side = nullptr;  // that chain's stream (context-owned, non-blocking)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_ee_fork = nullptr, ev_ee_join = nullptr;   // early-exit heads / probes of a layer on the side stream, beside the block's attention launch
     StepCoef* coef = nullptr;    // device [1000]
     StepCoef coef_host[1000];
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -70,7 +71,7 @@ struct BlockW {
     const bf16_t* qa_img;    // attn.qkv weight per head in fragment order (qkv_attention_pack) or null
 };
 
-struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; };
+struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred) or null
 
 struct GraphKey {
     const void* x; const void* y; int B, noise, variance, num_cus;   // num_cus: the captured persistent grids are sized from it
@@ -437,30 +438,45 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     bool skip_done = false; // ... and x already holds that block's skip_linear output (the previous fused launch ran it too)
     bool qkv_done = false;  // ... and qkv already holds that block's attn.qkv output (ditto)
     bool qa_ready = false;  // ... or only the extra-token rows of it: the patch rows' qkv is computed inside the attention launch
+    bool ee_side = false;   // this block's early-exit head / probe launches are in flight on the side stream
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
         if (ee) {
             // output head and uncertainty probe on the INPUT of block bi (for out-blocks: before skip_linear, as the
-            // reference taps x before blk(x, skip)); both read the fp32 residual stream
+            // reference taps x before blk(x, skip)); both read the fp32 residual stream.  In- and mid-blocks: on the context's side
+            // stream, beside this block's norm1 / qkv / attention launches (which only read x); joined before the first launch that
+            // writes x (attn.proj).  Out-blocks start with skip_linear, which overwrites x: their heads stay in line.
             const HeadW& hd = m->heads[bi];
-            float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
-            DD_HIP(c, launch_layernorm<float>(m->x, hd.ng, hd.nb, hf, M, D, s));
-            GemmArgs<float> g{hf, nullptr, hd.wdec, hd.bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
-            DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, s, c->num_cus));
+            ee_side = !is_out && c->side && s != c->side;
+            hipStream_t hs = ee_side ? c->side : s;
+            if (ee_side) {
+                DD_HIP(c, hipEventRecord(c->ev_ee_fork, s));
+                DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_ee_fork, 0));
+            }
+            if (hd.wg) {   // the head's LayerNorm + decoder_pred in one exact-fp32 launch (the final head's kernel), patch rows only
+                HeadDecArgs ha{m->x, hd.wg, hd.dc, m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
+                DD_HIP(c, launch_head_dec(ha, D, c->num_cus, hs));
+            } else {
+                float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
+                DD_HIP(c, launch_layernorm<float>(m->x, hd.ng, hd.nb, hf, M, D, hs));
+                GemmArgs<float> g{hf, nullptr, hd.wdec, hd.bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
+                DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, hs, c->num_cus));
+            }
             const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
             FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
                          c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
-            DD_HIP(c, launch_final(fa, s));
+            DD_HIP(c, launch_final(fa, hs));
             if (m->ee_type == DD_EE_ATTENTION_PROBE) {
-                DD_HIP(c, launch_ee_attn_probe(m->x, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, s));
+                DD_HIP(c, launch_ee_attn_probe(m->x, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, hs));
             } else {
                 // probe row: layer bi | timestep t | (t, layer): t is read from the step state inside the launch (a captured
                 // step replays for every t); dd_forward_early_exit has put int(t) there
                 const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
                 const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
-                DD_HIP(c, launch_ee_probe(m->x, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, B, L, D, c->st, t_mul, add, s));
+                DD_HIP(c, launch_ee_probe(m->x, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
             }
+            if (ee_side) DD_HIP(c, hipEventRecord(c->ev_ee_join, c->side));
         }
         if (is_out && !skip_done) {
             const int oi = bi - m->half_depth - 1;
@@ -492,6 +508,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
         }
         qkv_done = false; qa_ready = false;
+        if (ee_side) {     // the head / probe launches have read x: from here on the block updates it
+            DD_HIP(c, hipStreamWaitEvent(s, c->ev_ee_join, 0));
+            ee_side = false;
+        }
         if (!(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
@@ -753,7 +773,9 @@ int dd_ctx_create(int device, dd_ctx** out) {
               hipMemset(c->st2, 0, sizeof(StepState)) == hipSuccess &&
               hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_ee_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_ee_join, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
          init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess;
@@ -768,6 +790,8 @@ void dd_ctx_destroy(dd_ctx* c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_ee_fork) (void)hipEventDestroy(c->ev_ee_fork);
+    if (c->ev_ee_join) (void)hipEventDestroy(c->ev_ee_join);
     if (c->st) (void)hipFree(c->st);
     if (c->st2) (void)hipFree(c->st2);
     if (c->coef) (void)hipFree(c->coef);
@@ -879,7 +903,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
     m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
     m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
-    m->fused_qa = m->fused_proj && m->ee_type < 0 && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
+    // (early-exit models too: their heads and probes read the residual stream between blocks, which this launch does not touch)
+    m->fused_qa = m->fused_proj && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img; bool skip; };
     std::vector<BlockOff> boffs;
@@ -962,7 +987,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
-    struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv; };
+    struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv, wg, dc; };
     struct AttnProbeOff { size_t u, wvt, bv, w0t, b0, w2, b2; };
     std::vector<AttnProbeOff> aoffs;
     std::vector<HeadOff> hoffs;
@@ -975,6 +1000,19 @@ int dd_model_finalize(dd_model* m, int precision) {
             o.wdec = put_f32(P(p + "decoder_pred.weight").data(), (size_t)m->pd * D); o.bdec = put_f32(P(p + "decoder_pred.bias").data(), m->pd);
             o.wconv = put_f32(P(p + "final_layer.weight").data(), P(p + "final_layer.weight").size());
             o.bconv = put_f32(P(p + "final_layer.bias").data(), m->cfg.in_chans);
+            if (fused_head) {   // as the final head: dec = (W . diag(gamma)) xn + (b + W . beta)
+                const std::vector<float>&wd = P(p + "decoder_pred.weight"), &bd = P(p + "decoder_pred.bias"), &ng = P(p + "norm.weight"), &nbv = P(p + "norm.bias");
+                std::vector<float> wg((size_t)m->pd * D), dc(m->pd);
+                for (int r = 0; r < m->pd; ++r) {
+                    double acc = bd[r];
+                    for (int k = 0; k < D; ++k) {
+                        wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
+                        acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
+                    }
+                    dc[r] = (float)acc;
+                }
+                o.wg = put_f32(wg.data(), wg.size()); o.dc = put_f32(dc.data(), dc.size());
+            }
             hoffs.push_back(o);
         }
         if (m->ee_type == DD_EE_ATTENTION_PROBE) {
@@ -1033,7 +1071,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     }
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
-    for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv)});
+    for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv), fused_head ? F(o.wg) : nullptr, fused_head ? F(o.dc) : nullptr});
     if (m->ee_type >= 0 && m->ee_type != DD_EE_ATTENTION_PROBE) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
     for (const AttnProbeOff& o : aoffs) m->attn_probes.push_back(AttnProbeW{F(o.u), F(o.wvt), F(o.bv), F(o.w0t), F(o.b0), F(o.w2), F(o.b2)});
     if (fused_head) { m->wdec_g = F(o_wg); m->dec_c = F(o_dc); }

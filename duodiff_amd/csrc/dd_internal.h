@@ -242,8 +242,8 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
 // AttentionProbe operands of one layer (capi.hip finalize folds them): u [D], Wv^T [D, D], bv [D], W0^T [D, D], b0 [D], w2 [D], b2 [1]
 struct AttnProbeW { const float *u, *wvt, *bv, *w0t, *b0, *w2, *b2; };
 hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s);
-// probe row = (t_mul ? st->t_final * t_mul : 0) + add of the [n_probe, D] / [n_probe] tables
-hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, int B, int L, int D,
+// probe row = (t_mul ? st->t_final * t_mul : 0) + add of the [n_probe, D] / [n_probe] tables; srow: [B, L] fp32 scratch (the rows' sigmoids)
+hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, float* srow, int B, int L, int D,
                            const StepState* st, int t_mul, int add, hipStream_t s);
 // st != null: idx / err_mean are [1000, B] / [1000, depth] tables and row st->t_final is written
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
