@@ -62,6 +62,7 @@ def parse(argv=None):
     p.add_argument("--cpu_batch", type=int, default=0)
     p.add_argument("--cpu_steps", type=int, default=0)
     p.add_argument("--launch_timeout", type=float, default=3000.0, help="--gpus N self-launch: seconds before the parent gives up and stops its ranks")
+    p.add_argument("--num_cus", type=int, default=0, help="dd_set_num_cus: CU count the persistent GEMM grids are sized for (experiments)")
     p.add_argument("--dev_flags", type=int, default=0, help="dd_dev_set_flags value (include/duodiff_dev.h): same-process kernel-variant A/B runs only")
     return p.parse_args(argv)
 
@@ -237,6 +238,9 @@ def main():
         from duodiff_amd.engine import Context
         c0 = Context.get(dev)
         c0.check(c0.lib.dd_dev_set_flags(c0.handle, a.dev_flags))
+    if a.num_cus:
+        from duodiff_amd.engine import Context
+        Context.get(dev).set_num_cus(a.num_cus)
     shallow = UViT(**mp_s.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_s).to(dev)
     full = UViT(**mp_f.as_dict(), precision=a.precision, max_batch=B).load_state_dict(sd_f).to(dev)
     es, ef = shallow.engine_model(B), full.engine_model(B)
@@ -335,6 +339,8 @@ def main():
         #   else:     the fc1 GEMM (bias + GELU epilogue) of the two-GEMM path
         with torch.cuda.stream(stream):
             ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, y=y, stream=stream)
+            # ... and the same launches as the timed loop runs them when it splits the batch: two half-batch chains side by side
+            ms_ch, n_ch = ef.profile_steps_chained(x, t_start=699, steps=20, y=y, stream=stream) if chains == 2 else (None, 0)
         D_, H_ = mp_f.embed_dim, 4 * mp_f.embed_dim
         fused = a.precision == "bf16" and D_ in (64, 128, 256, 512)
         if fused:
@@ -360,6 +366,8 @@ def main():
             pmc_kernel = "gemm256_kernel<1>"
             kname = "gemm256_kernel<EPI_BIAS_GELU>: fc1 + bias + exact-erf GELU, M=%d K=%d N=%d" % (M_rows, D_, H_)
         ach = fl / (ms * 1e-3) / 1e12
+        # main row tiles of a half-batch launch: 128-row tiles of the patch rows (fused tail) / 256-row tiles x column tiles (fc1 GEMM)
+        main_tiles_half = ((B // 2) * mp_f.num_patches + 127) // 128 if fused else ((B // 2) * mp_f.seq_len // 256) * (H_ // 256)
         # HBM bytes / MFMA-busy fraction of that kernel: quoted from the COMMITTED rocprofv3 --pmc profile only when that profile
         # was collected on the build that is running (rocprofv3 cannot run inside this process); null + reason otherwise
         pm, why_not = committed_pmc(build_id, a.workload, pmc_kernel)
@@ -400,6 +408,14 @@ def main():
                                               f"of this build; not measured in this run") if mfma_busy else why_not,
                          "sclk_mhz_under_load": sclk,
                          "sclk_source": ("GRBM_GUI_ACTIVE / 8 / launch duration of the same committed profile (profiled passes clock 2-5 % below un-profiled ones)") if sclk else why_not,
+                         # the timed loop's own launches of this kernel (chains_in_timed_region == 2): half the batch per launch, the other
+                         # chain's kernels running beside it.  A launch of T main tiles holds T of the 256 CUs (one workgroup per CU: LDS), so
+                         # its own roof is peak x T / 256; `frac` above is the conservative figure (the kernel alone, every CU in the same phase)
+                         "chained": None if ms_ch is None else {
+                             "ms_per_launch": ms_ch, "launches_timed": n_ch, "flops_per_launch": fl / 2, "achieved": fl / 2 / (ms_ch * 1e-3) / 1e12,
+                             "main_tiles_per_launch": main_tiles_half, "cu_share": min(1.0, main_tiles_half / 256.0),
+                             "frac_of_the_cus_it_holds": fl / 2 / (ms_ch * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS * min(1.0, main_tiles_half / 256.0)),
+                             "ms_per_launch_source": "measured live (hipEvents on both chains' streams, eager steps)"},
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
                                            "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},

@@ -12,7 +12,7 @@ DD_PREC_BF16, DD_PREC_FP32 = 0, 1
 DD_VAR_BETA_TILDE, DD_VAR_BETA = 0, 1
 DD_NOISE_NONE, DD_NOISE_BUFFER, DD_NOISE_PHILOX = 0, 1, 2
 DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, DD_EE_ATTENTION_PROBE = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_EMBED, DD_DEV_MLP_EXTRAS_ONLY = 1, 2, 4, 8, 16
 DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV, DD_DEV_NO_FUSED_QA = 32, 64, 128
 DD_DEV_NO_CHAINS, DD_DEV_FORCE_CHAINS = 256, 512
@@ -85,6 +85,8 @@ SIGNATURES = {
     "dd_vae_destroy": (None, [C.c_void_p]),
     "dd_profile_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "dd_profile_steps_chained": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dd_dev_qkv_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),

@@ -1485,6 +1485,50 @@ int dd_profile_steps(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev,
     return DD_OK;
 }
 
+// dd_profile_steps for the way dd_sample runs a large batch: the two half-batch chains enqueued eagerly on `stream` and on the
+// context's side stream, step by step, with an event pair around every launch of the dominant kernel in BOTH chains -- the
+// launches overlap the other chain's kernels exactly as the graph replays of the timed loop do.
+int dd_profile_steps_chained(dd_ctx* c, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
+                             void* stream, float* ms_out, int* launches_out) {
+    int rc = check_call(c, m, B, y_dev);
+    if (rc) return rc;
+    if (!x_dev || !ms_out || steps < 1 || t_start > 999 || t_start - steps + 1 < 0 || (B & 1) || B < 2) return fail(c, DD_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_chain_ws(c, m))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int B0 = B / 2, B1 = B - B0;
+    const size_t chw = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    DD_HIP(c, hipEventRecord(c->ev_fork, s));
+    DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    m->time_fc1 = true;
+    m->fc1_used = 0;
+    for (int i = 0; i < steps && !rc; ++i) {
+        hipError_t e = launch_set_state(c->st, t_start - i, 12345ull, s);
+        if (e == hipSuccess) e = launch_set_state(c->st2, t_start - i, 12345ull, c->side);
+        if (e != hipSuccess) { m->time_fc1 = false; return fail_hip(c, e, "set_state"); }
+        rc = enqueue_step(c, m, x_dev, y_dev, DD_NOISE_PHILOX, nullptr, DD_VAR_BETA_TILDE, nullptr, B0, s);
+        if (rc) break;
+        swap_chain(m); std::swap(c->st, c->st2);
+        rc = enqueue_step(c, m, x_dev + (size_t)B0 * chw, y_dev ? y_dev + B0 : nullptr, DD_NOISE_PHILOX, nullptr, DD_VAR_BETA_TILDE, nullptr,
+                          B1, c->side, 0, nullptr, B0);
+        swap_chain(m); std::swap(c->st, c->st2);
+    }
+    m->time_fc1 = false;
+    if (rc) return rc;
+    DD_HIP(c, hipEventRecord(c->ev_join, c->side));
+    DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    DD_HIP(c, hipStreamSynchronize(s));
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < m->fc1_used; i += 2) {
+        float ms = 0.f;
+        DD_HIP(c, hipEventElapsedTime(&ms, m->fc1_events[i], m->fc1_events[i + 1]));
+        total += ms;
+    }
+    const int n = (int)(m->fc1_used / 2);
+    *ms_out = n ? (float)(total / n) : 0.f;
+    if (launches_out) *launches_out = n;
+    return DD_OK;
+}
+
 int dd_bench_gemm(dd_ctx* c, dd_model* m, int B, int iters, void* stream, float* ms_out, double* flops_out) {
     int rc = check_call(c, m, B, m && m->cfg.num_classes > 0 ? (const int64_t*)1 : nullptr);
     if (rc) return rc;

@@ -230,6 +230,14 @@ class Model:
                                                      x.shape[0], _stream_ptr(stream), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_steps_chained(self, x, t_start=699, steps=10, y=None, stream=None):
+        """The same with the batch split into dd_sample's two half-batch chains (the caller's stream + the context's side stream):
+        average ms of a half-batch launch of the dominant kernel while the other chain runs beside it."""
+        ms, n = C.c_float(), C.c_int()
+        self.ctx.check(self.ctx.lib.dd_profile_steps_chained(self.ctx.handle, self.handle, _ptr(x), _ptr(y), int(t_start), int(steps),
+                                                             x.shape[0], _stream_ptr(stream), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def bench_gemm(self, B, iters=20, stream=None):
         ms, fl = C.c_float(), C.c_double()
         self.ctx.check(self.ctx.lib.dd_bench_gemm(self.ctx.handle, self.handle, int(B), int(iters),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 3
+#define DD_ABI_VERSION 4
 
 typedef struct dd_ctx dd_ctx;
 typedef struct dd_model dd_model;
@@ -260,6 +260,11 @@ int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
  * and returns the average milliseconds per launch: what rocprofv3 --kernel-trace averages for that kernel. */
 int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
                      void* stream, float* fc1_ms_out, int* launches_out);
+/* The same measurement for the way dd_sample runs an even batch >= 32: TWO half-batch chains (images [0, B/2) on `stream`, the rest on
+ * the context's side stream), enqueued eagerly step by step, an event pair around every launch of the dominant kernel in both
+ * chains -- each timed launch covers B/2 images and overlaps the other chain's kernels as in the timed loop. */
+int dd_profile_steps_chained(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
+                             void* stream, float* ms_out, int* launches_out);
 
 /* Host-only: the row partition the 256x256 GEMM uses for C[M,N] = A[M,K] W[N,K]^T on `num_cus` CUs:
  * q main tiles of 256 rows + e (<= 8) tail rows per tile; DD_ERR_UNSUPPORTED if the shape falls back
