@@ -667,16 +667,21 @@ int stage_inputs(dd_ctx* c, const float* x_dev, const int64_t* y_dev, int B, siz
     return DD_OK;
 }
 
-// dd_sample splits an even batch of at least 32 images into two half-batch chains where that pays (same-box A/B, profiles/r04/
-// ab_chains.txt): the fused-path models (their kernels have strong MFMA / HBM phase structure and one tile per CU at the benchmark batch:
-// CelebA B = 128 +10.5 %), and GEMM-path models whose launches leave CUs idle (ImageNet-256 latents, B = 32: +7.7 %); NOT the GEMM
-// path at large batches (ImageNet-64, B = 256: its persistent grids fill every CU's LDS, two chains only queue behind each other:
-// -4.7 %).  Development flags force it on for any even batch, or switch it off.
+// dd_sample splits an even batch of at least 32 images into two half-batch chains (same-box A/B, profiles/r04/ab_chains.txt): the
+// fused-path models (their kernels have strong MFMA / HBM phase structure and one tile per CU at the benchmark batch: CelebA B = 128
+// +10.5 %) and GEMM-path models whose launches leave CUs idle (ImageNet-256 latents, B = 32: +9 %) as they are; GEMM-path models at
+// large batches (ImageNet-64, B = 256) with the persistent GEMM grids of both chains sized for HALF the CUs (chain_gemm_cus): a full-size
+// grid holds every CU's LDS, two of them only queue behind each other (-4.7 %), two half-size ones run side by side (+4.7 %).
+// Development flags force the split on for any even batch, or switch it off.
 bool use_chains(dd_ctx* c, dd_model* m, int B) {
     if ((c->dev_flags & DD_DEV_NO_CHAINS) || (B & 1) || B < 2 || m->ee_type >= 0) return false;
-    if (c->dev_flags & DD_DEV_FORCE_CHAINS) return true;
-    if (B < 32) return false;
-    return (m->prec == DD_PREC_BF16 && m->fused_mlp) || (long long)B * m->L <= 32768;
+    return B >= 32 || (c->dev_flags & DD_DEV_FORCE_CHAINS);
+}
+int chain_gemm_cus(dd_ctx* c, dd_model* m, int B) {
+    const bool fused = m->prec == DD_PREC_BF16 && m->fused_mlp;
+    if (fused || (long long)B * m->L <= 32768) return c->num_cus;
+    const int half = c->num_cus / 2 / 8 * 8;
+    return half >= 8 ? half : c->num_cus;
 }
 int ensure_chain_ws(dd_ctx* c, dd_model* m) {
     if (m->wsarena2) return DD_OK;
@@ -1260,6 +1265,9 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     c->last_chains = chained ? 2 : 1;
     if (a->use_graph) {
         if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, x_elems, s, &x_run, &y_run))) return rc;
+        // (the captured persistent GEMM grids are sized from c->num_cus: halved for both chains of a large GEMM-path batch)
+        struct CusGuard { dd_ctx* c; int saved; ~CusGuard() { c->num_cus = saved; } } cus_guard{c, c->num_cus};
+        if (chained) c->num_cus = std::min(chain_gemm_cus(c, a->first, a->B), switching ? chain_gemm_cus(c, a->late, a->B) : c->num_cus);
         GraphKey key{x_run, y_run, B0, a->noise_mode, a->variance, c->num_cus, nullptr};
         auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, a->variance, nullptr, B0, s, 1); };
         if ((rc = get_graph(c, a->first, 0, key, s, step))) return rc;

@@ -189,28 +189,33 @@ def test_switch_and_graph_replay_match_manual_steps():
     assert torch.isfinite(xm).all()
 
 
-@pytest.mark.parametrize("case", ["tiny_forced", "tiny_cond_forced", "celeba_default"])
+@pytest.mark.parametrize("case", ["tiny_forced", "tiny_cond_forced", "celeba_default", "imagenet64_gemm_path"])
 def test_half_batch_chains_equal_the_single_chain(case):
     """dd_sample runs an even batch of >= 32 images as two half-batch chains on two streams (each with its own workspace, step
     state and captured graphs; images are independent and a row's path through the kernels does not depend on the batch, the Philox
     pixel ids carry the image offset).  The result must equal the single-chain loop bit for bit: backbone switch inside the run,
     device noise; tiny models with the split forced at B = 6 (unconditional and class-conditional: the label half moves too),
-    and the CelebA pair at its benchmark batch with the default policy."""
+    the CelebA pair at its benchmark batch with the default policy, and two ImageNet-64 width models (embed_dim 768: the GEMM
+    sequence) at B = 256, where both chains' persistent GEMM grids are sized for half the CUs (another row partition, same values)."""
     from duodiff_amd import _lib as L
     from duodiff_amd.engine import sample_loop
     if case == "celeba_default":
         B, S, C_, steps, tsw, force = 128, 64, 3, 6, 3, 0
         cfg_s, cfg_f = load_config(REPO / "configs" / "uvit_celeba_3.yaml"), load_config(REPO / "configs" / "uvit_celeba.yaml")
+    elif case == "imagenet64_gemm_path":
+        B, S, C_, steps, tsw, force = 256, 64, 3, 4, 2, 0
+        cfg_s = cfg_f = load_config(REPO / "configs" / "uvit_imagenet64_3.yaml")
     else:
         B, S, C_, steps, tsw, force = 6, 8, 3, 12, 5, L.DD_DEV_FORCE_CHAINS
         nc = 10 if case == "tiny_cond_forced" else -1
         cfg_s, cfg_f = dict(TINY, depth=1, num_classes=nc), dict(TINY, depth=3, num_classes=nc)
     m_s, _ = _uvit(cfg_s, 31, "bf16", max_batch=B)
-    m_f, _ = _uvit(cfg_f, 32, "bf16", max_batch=B)
+    m_f, mp_f = _uvit(cfg_f, 32, "bf16", max_batch=B)
     es, ef = m_s.engine_model(B), m_f.engine_model(B)
     ctx = es.ctx
     x0 = torch.randn(B, C_, S, S, generator=torch.Generator().manual_seed(4)).cuda()
-    y = torch.randint(0, 10, (B,), generator=torch.Generator().manual_seed(5)).cuda() if case == "tiny_cond_forced" else None
+    ncls = int(mp_f.num_classes)
+    y = torch.randint(0, ncls, (B,), generator=torch.Generator().manual_seed(5)).cuda() if ncls > 0 else None
     stream = torch.cuda.Stream()
     stream.wait_stream(torch.cuda.current_stream())
     outs = {}
