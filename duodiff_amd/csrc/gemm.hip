@@ -742,7 +742,12 @@ hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int nu
     } else {
         Part256 p;
         const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
-        if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) return launch_256(a, epilogue, p, cus, s);
+        if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) {
+            // a launch whose 256 x 256 tiles would leave half of the grid's CUs without one (ImageNet-256 latents, B = 32: the N = 1024
+            // Linears have 32 x 4 tiles) takes the 128 x 128 kernel instead: four times the tiles, two workgroups per CU
+            if ((long long)p.q * (a.N / 256) * 2 <= cus && !a.hm.L) return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
+            return launch_256(a, epilogue, p, cus, s);
+        }
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);   // shapes the 256x256 kernel does not take (small N, tiny M)
     }
 }
