@@ -130,8 +130,8 @@ struct dd_model {
     bf16_t* hfrag = nullptr;              // fused_qa: norm1 of the patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
-    hipGraphExec_t graph[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
-    GraphKey gkey[4]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] DDPM step of the second chain
+    hipGraphExec_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
+    GraphKey gkey[5]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] / [4]: [0] / [1] of the second chain
     WsOffsets wsoff{};
     char* wsarena2 = nullptr;                                // the second chain's workspace (allocated by the first chained dd_sample)
     WsPtrs ws2;
@@ -1351,15 +1351,41 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
 
     float* x_run = a->x_dev;
     const int64_t* y_run = a->y_dev;
-    const size_t x_elems = (size_t)a->B * a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    const size_t chw = (size_t)a->first->cfg.in_chans * a->first->cfg.img_size * a->first->cfg.img_size;
+    const size_t x_elems = (size_t)a->B * chw;
+    // two half-batch chains, as dd_sample (both read the one step table; each has its own step index and Philox image offset)
+    const bool chained = a->use_graph && use_chains(c, a->first, a->B) && (!switching || use_chains(c, a->late, a->B));
+    const int B0 = chained ? a->B / 2 : a->B, B1 = a->B - B0;
+    c->last_chains = chained ? 2 : 1;
     if (a->use_graph) {
         if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, x_elems, s, &x_run, &y_run))) return rc;
-        const GraphKey key{x_run, y_run, a->B, a->noise_mode, 0, c->num_cus, c->atab};
-        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, 0, nullptr, a->B, s, 1, c->atab); };
+        struct CusGuard { dd_ctx* c; int saved; ~CusGuard() { c->num_cus = saved; } } cus_guard{c, c->num_cus};
+        if (chained) c->num_cus = std::min(chain_gemm_cus(c, a->first, a->B), switching ? chain_gemm_cus(c, a->late, a->B) : c->num_cus);
+        const GraphKey key{x_run, y_run, B0, a->noise_mode, 0, c->num_cus, c->atab};
+        auto step = [&](dd_model* m) { return enqueue_step(c, m, x_run, y_run, a->noise_mode, nullptr, 0, nullptr, B0, s, 1, c->atab); };
         if ((rc = get_graph(c, a->first, 1, key, s, step))) return rc;
         if (switching && (rc = get_graph(c, a->late, 1, key, s, step))) return rc;
+        if (chained) {
+            float* x1 = x_run + (size_t)B0 * chw;
+            const int64_t* y1 = y_run ? y_run + B0 : nullptr;
+            GraphKey key1{x1, y1, B1, a->noise_mode, 0, c->num_cus, c->atab};
+            key1.b0 = B0;
+            auto step1 = [&](dd_model* m) {
+                swap_chain(m); std::swap(c->st, c->st2);
+                const int r = enqueue_step(c, m, x1, y1, a->noise_mode, nullptr, 0, nullptr, B1, s, 1, c->atab, B0);
+                swap_chain(m); std::swap(c->st, c->st2);
+                return r;
+            };
+            if ((rc = ensure_chain_ws(c, a->first)) || (rc = get_graph(c, a->first, 4, key1, s, step1))) return rc;
+            if (switching && ((rc = ensure_chain_ws(c, a->late)) || (rc = get_graph(c, a->late, 4, key1, s, step1)))) return rc;
+        }
     }
     DD_HIP(c, launch_set_state_table(c->st, c->atab, (unsigned long long)a->seed, s));
+    if (chained) {
+        DD_HIP(c, launch_set_state_table(c->st2, c->atab, (unsigned long long)a->seed, s));
+        DD_HIP(c, hipEventRecord(c->ev_fork, s));
+        DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
     DD_HIP(c, hipEventRecord(c->ev[0], s));
     bool marked = false;
     dd_model* cur = a->first;
@@ -1371,10 +1397,15 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
         }
         if (a->use_graph) {
             DD_HIP(c, hipGraphLaunch(cur->graph[1], s));
+            if (chained) DD_HIP(c, hipGraphLaunch(cur->graph[4], c->side));
         } else {
             rc = enqueue_step(c, cur, x_run, y_run, a->noise_mode, nullptr, 0, nullptr, a->B, s, 1, c->atab);
             if (rc) return rc;
         }
+    }
+    if (chained) {
+        DD_HIP(c, hipEventRecord(c->ev_join, c->side));
+        DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
     }
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));

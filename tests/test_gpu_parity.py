@@ -235,6 +235,33 @@ def test_half_batch_chains_equal_the_single_chain(case):
     assert torch.equal(outs["chained"][0], outs["single"][0]), "two half-batch chains differ from the single chain"
 
 
+def test_half_batch_chains_in_the_table_driven_loops():
+    """dd_sample_affine (DDIM with eta > 0, predict_original, predict_previous: device Philox noise, backbone switch) split into two
+    half-batch chains must equal the single-chain loop bit for bit (both chains read the one step table; the Philox ids carry the
+    image offset)."""
+    from duodiff_amd import _lib as L
+    from duodiff_amd import sampler
+    m_s, _ = _uvit(dict(TINY, depth=1), 300, "bf16", max_batch=6)
+    m_f, _ = _uvit(dict(TINY, depth=3), 301, "bf16", max_batch=6)
+    ctx = m_s.engine_model(6).ctx
+    run = lambda **kw: sampler.get_samples(m_s, 6, kw.pop("post", sampler.predict_noise_postprocessing), 5, 3, 8, 8,
+                                           late_model=m_f, noise="device", **kw)
+    try:
+        for kw in (dict(use_ddim=True, ddim_steps=30, ddim_eta=0.05, t_switch=400),
+                   dict(post=sampler.predict_original_postprocessing, num_steps=40, t_switch=980),
+                   dict(post=sampler.predict_previous_postprocessing, num_steps=30, t_switch=985, timesteps_save=[4, 20])):
+            outs = []
+            for flags in (L.DD_DEV_FORCE_CHAINS, L.DD_DEV_NO_CHAINS):
+                ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+                g, gi = run(**dict(kw))
+                outs.append((g, gi, ctx.lib.dd_dev_last_sample_chains(ctx.handle)))
+            assert outs[0][2] == 2 and outs[1][2] == 1
+            assert np.isfinite(outs[1][0]).all() and np.array_equal(outs[0][0], outs[1][0]), f"{kw}: chained loop differs"
+            assert len(outs[0][1]) == len(outs[1][1]) and all(np.array_equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    finally:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+
+
 def test_graphs_are_not_recaptured_for_new_tensors():
     """reference get_samples allocates a fresh x per call (sampler.py:98); dd_sample's graphs run on context-owned staging
     buffers, so a second call with other tensors of the same shape replays the captured graphs (and still writes its
