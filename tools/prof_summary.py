@@ -11,6 +11,16 @@ for r in rows[:14]:
     print(f"{clean(r['Name'])[:86]:86s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:8.1f} pct={float(r['TotalDurationNs'])/tot*100:5.1f}")
 tr = list(csv.DictReader(open(trace)))
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the same kernel runs at two grid sizes when dd_sample splits the batch into two half-batch chains (the timed loop: half-batch launches,
+# two chains side by side) next to bench.py's stand-alone roofline leg (full-batch launches): one line per (kernel, workgroups)
+import collections
+by = collections.defaultdict(list)
+for r in tr:
+    wg = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1))
+    by[(clean(r["Kernel_Name"])[:70], wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("== per (kernel, workgroups per launch)")
+for (n, wg), v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:20]:
+    print(f"{n:70s} wgs={wg:6d} calls={len(v):6d} avg_us={sum(v) / len(v) / 1e3:8.1f} total_ms={sum(v) / 1e6:8.2f}")
 idx = [i for i, r in enumerate(tr) if "embed_" in r["Kernel_Name"]]
 seq = tr[idx[-2]:idx[-1]]
 t0 = int(seq[0]["Start_Timestamp"])
