@@ -20,6 +20,7 @@
 #include "dd_internal.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace dd {
 namespace {
@@ -454,25 +455,53 @@ struct QkvAttnArgs {
 // LDS behind the K / V images: px = the extra rows' partial q / k / v sums [8 waves][6 tiles][2 rows][32 columns] fp32 (the split
 // chunk's [8 waves][2 queries][64 d, max, sum] fp32 reuses its start later) | hxl = the extra rows of h [2][D] bf16 | qxl = their q [2][64] bf16
 constexpr int kQaPxBytes = 8 * 6 * 2 * 32 * 4;
-constexpr int kQaAuxBytes = kQaPxBytes + 2 * 1024 + 256;
+constexpr int kQaHxBytes = 2 * 1024 * 2;             // two rows of D <= 1024 bf16
+constexpr int kQaAuxBytes = kQaPxBytes + kQaHxBytes + 256;
+constexpr int kQaKQ = 8;                             // k-steps per slice of the k range
+constexpr int kQaBlk = 2 * kQaKQ * 1024;             // one weight block = (slice, tile pair): 2 x 8 k-steps x 1 KB fragments
+constexpr int kQaRing = 4 * kQaBlk;
 static_assert(8 * 2 * 66 * 4 <= kQaPxBytes, "the split chunk's partials reuse the px area");
+
+typedef const __attribute__((address_space(1))) void* qa_gptr_t;
+typedef __attribute__((address_space(3))) void* qa_lptr_t;
+
+// Phase A since round 4 -- the k range in SLICES of 8 k-steps, all six accumulators resident, the rows double-buffered:
+//   for slice q: [rows of h, k-steps 8 q .. 8 q + 7, as 32 VGPRs of B fragments; slice q + 1 is requested into the other 32 now]
+//       for tile pair (q0 q1), (k0 k1), (v0 v1):  acc[t] += W(q, t) . h_q^T      (one 16 KB weight block = 2 tiles x 8 k-steps, 16 MFMAs per wave)
+// The row fetch is bandwidth, not latency (256 KB per workgroup at the ~23 B/clk a CU takes in: 5 us, which the round-3 kernel waited
+// out before its first MFMA): here the first MFMA waits for an eighth of it (D = 512: a quarter) and every later slice arrives under
+// the three blocks of the slice before.  The weight blocks stream through a ring of four 16 KB slots requested three blocks ahead
+// (counted vmcnt; the old two-slot ring of whole 32 KB tiles was requested one tile ahead and drained with vmcnt(0)), and the bias /
+// pack / LDS-image epilogue runs once, after the last slice.  It is also what lets embed_dim 768 / 1024 in: their rows (192 / 256
+// fragment registers) never fit beside the accumulators at two waves per SIMD.
+// VMEM bookkeeping (hipcc counts neither the asm loads nor what an LDS-DMA piece covers): every vmcnt below is the exact number of
+// requests issued behind the one waited for (qa_younger_*), from the fixed issue order of a block:
+//   [wait: this block's LDS-DMA pieces] barrier [LDS-DMA of block + 3] [first block of a slice: wait: this slice's rows; request the next slice's]
+constexpr int qa_dma_ops(int b, int nb) { return b < nb ? 2 : 0; }                         // LDS-DMA pieces per wave of block b (none past the end)
+constexpr int qa_pref_ops(int b, int nb) { return (b % 3 == 0 && b / 3 + 1 < nb / 3) ? kQaKQ : 0; }   // row requests issued in block b (for the next slice)
+// requests younger than block b's LDS-DMA (issued first thing in block b - 3) when block b waits for it
+constexpr int qa_younger_dma(int b, int nb) {
+    return qa_pref_ops(b - 3, nb) + qa_dma_ops(b + 1, nb) + qa_pref_ops(b - 2, nb) + qa_dma_ops(b + 2, nb) + qa_pref_ops(b - 1, nb);
+}
+// requests younger than the rows of the slice that starts at block b (requested in block b - 3, behind that block's LDS-DMA) when
+// block b, having issued its own LDS-DMA, waits for them
+constexpr int qa_younger_rows(int b, int nb) { return qa_dma_ops(b + 1, nb) + qa_dma_ops(b + 2, nb) + qa_dma_ops(b + 3, nb); }
 
 template <int D>
 __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs a) {
     using Lay = AttnLayout<bf16_t>;
-    constexpr int KS = D / 16, BLK = KS * 1024, PPW = BLK / 1024 / 8;   // k-steps, bytes per weight tile, 1 KB DMA pieces per wave
-    static_assert(BLK % 8192 == 0, "a weight tile is DMA'd as 1 KB pieces spread evenly over 8 waves");
+    constexpr int KS = D / 16, NS = KS / kQaKQ, NB = 3 * NS;   // k-steps, slices, weight blocks of this head
+    static_assert(D % 128 == 0 && D >= 512 && D <= 1024, "k range in slices of 8 k-steps; hxl holds two rows of D <= 1024");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vt = smem + kLP * Lay::kRowK;
-    static_assert(D * 2 == 1024, "hxl holds two rows of D bf16 in 2 KB");
     float* px = reinterpret_cast<float*>(smem + kLP * Lay::kRowK + Lay::kVBytes);
     float* part = px;
     char* hxl = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaPxBytes;
-    char* qxl = hxl + 2 * 1024;
+    char* qxl = hxl + kQaHxBytes;
     char* ring = smem + kLP * Lay::kRowK + Lay::kVBytes + kQaAuxBytes;
 
-    // XCD-aware placement (workgroup i runs on XCD i % 8): the H heads of an image read the same 256 KB of h, so they take
+    // XCD-aware placement (workgroup i runs on XCD i % 8): the H heads of an image read the same rows of h, so they take
     // consecutive slots of ONE XCD and its L2 fetches those rows once
     int b, hh;
     if ((a.B & 7) == 0) { const int slot = blockIdx.x >> 3; b = (blockIdx.x & 7) + 8 * (slot / a.H); hh = slot % a.H; }
@@ -480,47 +509,61 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, r32 = lane & 31;
     const int L = a.L, E = a.E;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
 
-    // ---- this wave's 32 rows of h as B fragments (k-step ks: k = 16 ks + 8 half .. + 7): the fused block tail left them in exactly
-    // this order ([32-row group][k-step][lane] x 16 bytes: MlpFusedArgs::ln_out_frag), one contiguous KB per load instruction
-    const int row = 32 * wave + r32;                                   // image row = patch index
-    const bf16x8* hfr = reinterpret_cast<const bf16x8*>(a.h) + ((long long)b * 8 + wave) * KS * 64 + lane;
-    bf16x8 xf[KS];
+    const char* wsrc = reinterpret_cast<const char*>(a.wimg) + (size_t)hh * NB * kQaBlk + lane * 16;
+    auto dma_block = [&](int bb) {      // block bb -> ring slot bb & 3: two 1 KB pieces per wave
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = hfr[ks * 64];
-
-    const char* wsrc = reinterpret_cast<const char*>(a.wimg) + (size_t)hh * 6 * BLK + lane * 16;
-    auto dma_tile = [&](int j) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i;
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)j * BLK + p * 1024), (lptr_t)(ring + (j & 1) * BLK + p * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave * 2 + i;
+            __builtin_amdgcn_global_load_lds((qa_gptr_t)(wsrc + (size_t)bb * kQaBlk + pc * 1024), (qa_lptr_t)(ring + (bb & 3) * kQaBlk + pc * 1024), 16, 0, 0);
         }
     };
-    dma_tile(0);
+    dma_block(0);
+    dma_block(1);
+    dma_block(2);
 
-    // ---- the extra tokens' rows of h into LDS (every wave reads its k range of them in every tile); zero rows behind the images' last
+    // ---- this wave's 32 rows of h, part 0, as B fragments (k-step ks: k = 16 ks + 8 half .. + 7): the producer left them in exactly
+    // this order ([32-row group][k-step][lane] x 16 bytes: MlpFusedArgs::ln_out_frag / launch_layernorm_frag), 1 KB per load instruction
+    const int row = 32 * wave + r32;                                   // image row = patch index
+    const bf16x8* hfr = reinterpret_cast<const bf16x8*>(a.h) + ((long long)b * 8 + wave) * KS * 64 + lane;
+    bf16x8 xs[2][kQaKQ];                                               // slice q lives in set q & 1
+#pragma unroll
+    for (int ks = 0; ks < kQaKQ; ++ks) xs[0][ks] = hfr[ks * 64];
+
+    // ---- the extra tokens' rows of h into LDS (every wave reads its k range of them in every block); zero rows behind the images' last
     if (a.hx) {
-        if (tid < E * 64) *reinterpret_cast<f32x4*>(hxl + tid * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + (tid >> 6)) * D + (tid & 63) * 8);
-    } else if (wave < E) {     // wave e normalises extra row e: 8 columns per lane
-        const float* xr = a.xres + ((long long)b * L + wave) * D + lane * 8;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
-        float s1 = (x0[0] + x0[1]) + (x0[2] + x0[3]) + (x1[0] + x1[1]) + (x1[2] + x1[3]);
+        for (int i = tid; i < E * (D / 8); i += 512) {
+            const int e = i / (D / 8), cch = i % (D / 8);
+            *reinterpret_cast<f32x4*>(hxl + e * (D * 2) + cch * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + e) * D + cch * 8);
+        }
+    } else if (wave < E) {     // wave e normalises extra row e (two-pass statistics, fp32): D / 64 columns per lane
+        constexpr int NV = D / 256;
+        const float* xr = a.xres + ((long long)b * L + wave) * D + lane * (D / 64);
+        f32x4 xv[NV];
+        float s1 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xv[v] = *reinterpret_cast<const f32x4*>(xr + 4 * v);
+            s1 += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o);
         const float mean = s1 / (float)D;
-        const f32x4 d0 = x0 - mean, d1 = x1 - mean;
-        float s2 = (d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3]) + (d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]);
+        float s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xv[v] = xv[v] - mean;
+            s2 += (xv[v][0] * xv[v][0] + xv[v][1] * xv[v][1]) + (xv[v][2] * xv[v][2] + xv[v][3] * xv[v][3]);
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
         const float rstd = 1.0f / sqrtf(s2 / (float)D + 1e-5f);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + lane * 8 + 4);
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * 8), c1 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * 8 + 4);
-        const f32x4 y0 = d0 * rstd * g0 + c0, y1 = d1 * rstd * g1 + c1;
-        *reinterpret_cast<uint4*>(hxl + wave * (D * 2) + lane * 16) =
-            uint4{pack2_bf16(y0[0], y0[1]), pack2_bf16(y0[2], y0[3]), pack2_bf16(y1[0], y1[1]), pack2_bf16(y1[2], y1[3])};
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + lane * (D / 64) + 4 * v), c0 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * (D / 64) + 4 * v);
+            const f32x4 y = xv[v] * rstd * g + c0;
+            *reinterpret_cast<uint2*>(hxl + wave * (D * 2) + (lane * (D / 64) + 4 * v) * 2) = uint2{pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3])};
+        }
     }
     for (int i = tid; i < (kLP - 256 - E) * 16; i += 512) {
         const int r = 256 + E + (i >> 4), c = i & 15;
@@ -528,66 +571,91 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     }
 
     // ---- phase A
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = zero16;
+    // extras on 16x16x32 MFMAs: lane l supplies A = W[column 16 (wave & 1) + (l & 15)][k = 32 (wave >> 1) + 8 (l >> 4) .. + 7] of a tile, which sits
+    // in fragment (k-step 2 (wave >> 1) + (l >> 5)) at lane slot (column + 32 ((l >> 4) & 1)); and B = h[extra row (l & 15)][the same k]
+    f32x4 accx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xg = lane >> 4, xn = lane & 15;
+    const int wx16 = (2 * (wave >> 1) + (xg >> 1)) * 1024 + ((16 * (wave & 1) + xn) + 32 * (xg & 1)) * 16;
+    const char* hx16 = hxl + (xn < E ? xn : 0) * (D * 2) + (wave >> 1) * 64 + xg * 16;
+    [&]<int... BI>(std::integer_sequence<int, BI...>) {
+        ([&] {
+            constexpr int bb = BI, q = bb / 3, jj = bb % 3, S = q & 1;
+            // this wave's pieces of block bb have landed (in-order returns; the exact count of younger requests: qa_younger_dma)
+            if constexpr (bb == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (and slice 0 of the rows, hxl, the zero rows)
+            else if constexpr (bb < 3) asm volatile("s_barrier" ::: "memory");                                              // (landed with the wait of block 0)
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(qa_younger_dma(bb, NB)) : "memory");
+            // ... everyone's have, and nobody still reads the slot block bb + 3 goes to (block bb - 1's)
+            if constexpr (bb + 3 < NB) dma_block(bb + 3);
+            if constexpr (jj == 0) {
+                if constexpr (q > 0) {      // this slice's rows (requested three blocks ago): one wait, tied to the registers it guards
+                    asm volatile("s_waitcnt vmcnt(%8)"
+                                 : "+v"(xs[S][0]), "+v"(xs[S][1]), "+v"(xs[S][2]), "+v"(xs[S][3]), "+v"(xs[S][4]), "+v"(xs[S][5]), "+v"(xs[S][6]), "+v"(xs[S][7])
+                                 : "i"(qa_younger_rows(bb, NB)));
+                }
+                if constexpr (q + 1 < NS) {  // the next slice's rows into the other set (last read in the block before this one)
+#pragma unroll
+                    for (int ks = 0; ks < kQaKQ; ++ks)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xs[S ^ 1][ks]) : "v"(hfr + ((q + 1) * kQaKQ + ks) * 64) : "memory");
+                }
+            }
+            const char* wb = ring + (bb & 3) * kQaBlk + lane * 16;
+            // weight fragments four ahead of their MFMAs: fragment f = tile 2 jj + (f >> 3), k-step f & 7 of the slice
+            bf16x8 wq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+#pragma unroll
+            for (int f = 0; f < 2 * kQaKQ; ++f) {
+                const bf16x8 w0 = wq[f & 3];
+                if (f + 4 < 2 * kQaKQ) wq[f & 3] = *reinterpret_cast<const bf16x8*>(wb + (f + 4) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2 * jj + (f >> 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xs[S][f & 7], acc[2 * jj + (f >> 3)], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the extra tokens' rows against this block, on v_mfma_f32_16x16x32_bf16 (M = 16 of the tile's 32 columns, N = 16 "rows" of which
+            // the first E are the extra tokens, K = 32): wave w takes column half w & 1 and k-block w >> 1 of the slice's four, one small
+            // MFMA per tile, accumulated over ALL slices in 4 registers per tile -- no LDS round trip per block (the 32x32 form with its
+            // partial sums read-modify-written in LDS cost 45 % of phase A for 0.4 % of the rows); the waves' partial sums meet in LDS once,
+            // after the last slice.  The A fragment is gathered from the block's 32x32x16 fragment order with one 16-byte read per lane.
+            {
+                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hx16 + q * (kQaKQ * 32));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 wa = *reinterpret_cast<const bf16x8*>(ring + (bb & 3) * kQaBlk + t * (kQaKQ * 1024) + wx16);
+                    accx[2 * jj + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb, accx[2 * jj + t], 0, 0, 0);
+                }
+            }
+        }(), ...);
+    }(std::make_integer_sequence<int, NB>{});
+
+    // the extras' partial sums of this wave: lanes (l & 15) < E hold, for tile j, columns 16 (wave & 1) + 4 (l >> 4) .. + 3 of extra row l & 15
+    if (xn < E) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(px + (((wave * 6 + j) * 2 + xn) * 16 + 4 * xg)) = accx[j];
+    }
+    // ---- q stays in registers (its accumulators, packed to bf16, are the B fragments of S^T = K Q^T in accumulator k order), k and v
+    // go to the LDS images the attention core reads (K rows in that same accumulator order, V row-major)
     f32x4 qcur[4];
     const int swk = (row >> 1) & 7, swv = 2 * (row & 3);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile j have landed (hipcc does not track LDS-DMA writes)
-        __syncthreads();                                    // ... everyone's have, and nobody still reads the slot tile j + 1 goes to
-        const char* wb = ring + (j & 1) * BLK + lane * 16;
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // weight fragments four k-steps ahead of their MFMAs (the reads go out BEFORE the pair of MFMAs two steps older: hipcc
-        // otherwise issues read, read, wait, MFMA, MFMA and the LDS latency shows on every pair)
-        bf16x8 wq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
-        f32x16 acc0 = zero16, acc1 = zero16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks += 2) {
-            const bf16x8 w0 = wq[ks & 3], w1 = wq[(ks + 1) & 3];
-            if (ks + 4 < KS) {
-                wq[ks & 3] = *reinterpret_cast<const bf16x8*>(wb + (ks + 4) * 1024);
-                wq[(ks + 1) & 3] = *reinterpret_cast<const bf16x8*>(wb + (ks + 5) * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks + 1], acc1, 0, 0, 0);
-            // the next tile's DMA requests, one per MFMA pair from the second pair on: their issue cost (~70 clocks each) then sits in
-            // the shadow of this wave's and its SIMD neighbour's MFMAs instead of in front of the tile
-            if (j + 1 < 6 && ks >= 2 && ks / 2 - 1 < PPW) {
-                const int p = wave * PPW + (ks / 2 - 1);
-                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)(j + 1) * BLK + p * 1024), (lptr_t)(ring + ((j + 1) & 1) * BLK + p * 1024), 16, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x16 acc = acc0 + acc1;
-        {   // the extra tokens' rows against this tile: k-steps [wave KS/8, (wave + 1) KS/8) only -- the 8 waves' partial sums meet in LDS
-            // (a ninth row group's worth of MFMAs spread evenly: + 1/8 on phase A; placing them between the main MFMAs measured the same)
-            f32x16 accx = zero16;
-            const char* hxb = hxl + (r32 < E ? r32 : 0) * (D * 2) + 16 * half;
-#pragma unroll
-            for (int i = 0; i < KS / 8; ++i) {
-                const int ks = wave * (KS / 8) + i;
-                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), *reinterpret_cast<const bf16x8*>(hxb + ks * 32), accx, 0, 0, 0);
-            }
-            if (r32 < E) {
-                float* pp = px + ((wave * 6 + j) * 2 + r32) * 32 + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(pp + 8 * g) = f32x4{accx[4 * g], accx[4 * g + 1], accx[4 * g + 2], accx[4 * g + 3]};
-            }
-        }
         if (a.bias) {
             const float* bj = a.bias + (j >> 1) * D + hh * kHD + 32 * (j & 1) + 4 * half;   // register e: column (e & 3) + 8 (e >> 2) + 4 half
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bj + 8 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] += bv[e];
+                for (int e = 0; e < 4; ++e) acc[j][4 * g + e] += bv[e];
             }
         }
         unsigned pk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = pack2_bf16(acc[2 * i], acc[2 * i + 1]);
+        for (int i = 0; i < 8; ++i) pk[i] = pack2_bf16(acc[j][2 * i], acc[j][2 * i + 1]);
         const int T = j & 1;
         if (j < 2) {            // q: registers 8 eh .. 8 eh + 7 of d tile T are k-step 2 T + eh of S^T = K Q^T
             qcur[2 * T] = __builtin_bit_cast(f32x4, uint4{pk[0], pk[1], pk[2], pk[3]});
@@ -606,7 +674,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
         const int e = tid / 192, c = tid % 192, j = c >> 5, col = c & 31;
         float v = a.bias ? a.bias[(j >> 1) * D + hh * kHD + 32 * (j & 1) + col] : 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += px[((w * 6 + j) * 2 + e) * 32 + col];
+        for (int kb = 0; kb < 4; ++kb) v += px[(((2 * kb + (col >> 4)) * 6 + j) * 2 + e) * 16 + (col & 15)];   // k-blocks in ascending order
         const bf16_t vb = f2bf(v);
         const int d = 32 * (j & 1) + col, r = 256 + e;
         if (j < 2) {
@@ -705,36 +773,44 @@ hipError_t launch_attention(const T* qkv, T* out, int B, int L, int H, int D, hi
     return hipGetLastError();
 }
 
-// attn.qkv weight [3 D, D] (nn.Linear layout) -> per head the six 32-column tiles q0 q1 k0 k1 v0 v1 in MFMA A-fragment order:
-// img[((head * 6 + j) * D / 16 + ks) * 512 + lane * 8 + i] = W[(j >> 1) D + 64 head + 32 (j & 1) + (lane & 31)][16 ks + 8 (lane >> 5) + i]
+// attn.qkv weight [3 D, D] (nn.Linear layout) -> per head the weight blocks the kernel streams, in stream order: [slice q of the k range:
+// 8 k-steps][tile pair jj][tile t of the pair][k-step][lane] x 16 bytes (tiles j = 2 jj + t = q0 q1 k0 k1 v0 v1), each 1 KB fragment in
+// MFMA A-operand order:
+// img[(((((head * NS + q) * 3 + jj) * 2 + t) * 8 + ks) * 64 + lane) * 8 + i] = W[(j >> 1) D + 64 head + 32 (j & 1) + (lane & 31)][16 (8 q + ks) + 8 (lane >> 5) + i]
 void qkv_attention_pack(int D, int H, const float* w, unsigned short (*to_bf16)(float), unsigned short* img) {
-    const int KS = D / 16;
+    const int NS = D / 16 / kQaKQ;
     for (int hh = 0; hh < H; ++hh)
-        for (int j = 0; j < 6; ++j)
-            for (int ks = 0; ks < KS; ++ks)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const float* src = w + ((size_t)(j >> 1) * D + 64 * hh + 32 * (j & 1) + (lane & 31)) * D + 16 * ks + 8 * (lane >> 5);
-                    unsigned short* dst = img + (((size_t)hh * 6 + j) * KS + ks) * 512 + lane * 8;
-                    for (int i = 0; i < 8; ++i) dst[i] = to_bf16(src[i]);
-                }
+        for (int q = 0; q < NS; ++q)
+            for (int j = 0; j < 6; ++j)
+                for (int ks = 0; ks < kQaKQ; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const float* src = w + ((size_t)(j >> 1) * D + 64 * hh + 32 * (j & 1) + (lane & 31)) * D + 16 * (q * kQaKQ + ks) + 8 * (lane >> 5);
+                        unsigned short* dst = img + (((((size_t)hh * NS + q) * 6 + j) * kQaKQ + ks) * 64 + lane) * 8;
+                        for (int i = 0; i < 8; ++i) dst[i] = to_bf16(src[i]);
+                    }
 }
 
 bool qkv_attention_supported(int D, int H, int L, int extras) {
-    return D == 512 && H * kHD == D && (extras == 1 || extras == 2) && L == 256 + extras;
+    return (D == 512 || D == 768 || D == 1024) && H * kHD == D && (extras == 1 || extras == 2) && L == 256 + extras;
 }
 
-static size_t qkv_attention_lds(int D) { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaAuxBytes + (size_t)2 * (D / 16) * 1024; }
+static size_t qkv_attention_lds() { return (size_t)kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kQaAuxBytes + kQaRing; }
 
 hipError_t launch_qkv_attention(const bf16_t* h, const bf16_t* wimg, const float* bias, const bf16_t* hx, const float* xres,
                                 const float* ln_g, const float* ln_b, bf16_t* out, int B, int L, int H, int D, int extras, hipStream_t s) {
     if (!qkv_attention_supported(D, H, L, extras) || !h || !wimg || (!hx && (!xres || !ln_g || !ln_b)) || !out || B < 1) return hipErrorInvalidValue;
     const QkvAttnArgs a{h, wimg, bias, hx, xres, ln_g, ln_b, out, B, L, H, make_head_major(L, H).Lp, extras};
-    hipLaunchKernelGGL((qkv_attention_kernel<512>), dim3(B * H), dim3(512), qkv_attention_lds(512), s, a);
+    switch (D) {
+        case 512: hipLaunchKernelGGL((qkv_attention_kernel<512>), dim3(B * H), dim3(512), qkv_attention_lds(), s, a); break;
+        case 768: hipLaunchKernelGGL((qkv_attention_kernel<768>), dim3(B * H), dim3(512), qkv_attention_lds(), s, a); break;
+        default: hipLaunchKernelGGL((qkv_attention_kernel<1024>), dim3(B * H), dim3(512), qkv_attention_lds(), s, a); break;
+    }
     return hipGetLastError();
 }
 
 hipError_t init_attention_kernels() {
-    if (hipError_t e = hipFuncSetAttribute((const void*)qkv_attention_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qkv_attention_lds(512)); e != hipSuccess) return e;
+    for (const void* f : {(const void*)qkv_attention_kernel<512>, (const void*)qkv_attention_kernel<768>, (const void*)qkv_attention_kernel<1024>})
+        if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qkv_attention_lds()); e != hipSuccess) return e;
     const int lb = kLP * AttnLayout<bf16_t>::kRowK + AttnLayout<bf16_t>::kVBytes + kPartBytes;
     const int lf = kLP * AttnLayout<float>::kRowK + AttnLayout<float>::kVBytes + kPartBytes;
     hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);

@@ -909,7 +909,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
     m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
     // (early-exit models too: their heads and probes read the residual stream between blocks, which this launch does not touch)
-    m->fused_qa = m->fused_proj && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
+    // (embed_dim 768 / 1024 too, which have no fused block tail: their norm1 launch writes the fragment order, the qkv tensor is gone)
+    m->fused_qa = precision == DD_PREC_BF16 && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img; bool skip; };
     std::vector<BlockOff> boffs;
@@ -1715,7 +1716,7 @@ int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float
                          unsigned short* out_host, int iters, void* stream, float* ms_out) {
     if (!c || !h_host || !wqkv || !out_host) return DD_ERR_INVALID;
     const int D = 64 * H;
-    if (!qkv_attention_supported(D, H, L, extras)) return fail(c, DD_ERR_UNSUPPORTED, "qkv_attention: D = 512, L = 256 + 1 or 2 extra tokens only");
+    if (!qkv_attention_supported(D, H, L, extras)) return fail(c, DD_ERR_UNSUPPORTED, "qkv_attention: D = 512 / 768 / 1024, L = 256 + 1 or 2 extra tokens only");
     hipStream_t s = (hipStream_t)stream;
     const size_t M = (size_t)B * L;
     std::vector<unsigned short> hb(M * D), hf((size_t)B * 256 * D), img((size_t)3 * D * D);

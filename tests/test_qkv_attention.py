@@ -1,7 +1,7 @@
 """GPU unit test of the attention launch that computes attn.qkv itself (csrc/attention.hip qkv_attention_kernel) through its
 development entry point dd_dev_qkv_attention (include/duodiff_dev.h), against a float64 reference built from the SAME
 bf16-rounded operands: qkv = Linear(h), q, k, v rounded to bf16 (as the stored qkv tensor of the plain path is),
-softmax(q k^T / 8) v per (image, head).  Replaces reference models/uvit.py:152-164 for D = 512, L = 256 + 1 or 2.
+softmax(q k^T / 8) v per (image, head).  Replaces reference models/uvit.py:152-164 for D = 512 / 768 / 1024, L = 256 + 1 or 2.
 Covers: both extra-token counts, with and without qkv bias, batch sizes on both workgroup -> (image, head) maps
 (B % 8 == 0: XCD-grouped heads), the extra tokens as keys AND as queries.
 """
@@ -31,15 +31,17 @@ def _reference(h, w, bias, B, L, H):
     return (p @ v).transpose(0, 2, 1, 3).reshape(B * L, D)                               # "B H L D -> B L (H D)"
 
 
-@pytest.mark.parametrize("B,extras,with_bias", [(3, 1, False), (8, 2, False), (5, 2, True), (16, 1, True)])
-def test_qkv_attention_against_float64_reference(B, extras, with_bias):
+@pytest.mark.parametrize("B,extras,with_bias,H", [(3, 1, False, 8), (8, 2, False, 8), (5, 2, True, 8), (16, 1, True, 8),
+                                                  (3, 2, False, 12), (8, 2, True, 12), (2, 2, True, 16), (8, 1, False, 16)])
+def test_qkv_attention_against_float64_reference(B, extras, with_bias, H):
+    """H = 8 / 12 / 16 = embed_dim 512 / 768 / 1024: the k range of the Linear is walked in 2 / 3 / 4 parts of 16 k-steps."""
     from duodiff_amd.engine import Context
     ctx = Context.get()
-    H, D, L = 8, 512, 256 + extras
+    D, L = 64 * H, 256 + extras
     g = np.random.default_rng(100 * B + extras)
     h = g.standard_normal((B * L, D), dtype=np.float32)
     # weights scaled so that the scores spread over a few units (a flat softmax would hide a wrong key order)
-    w = (g.standard_normal((3 * D, D), dtype=np.float32) * 0.09).astype(np.float32)
+    w = (g.standard_normal((3 * D, D), dtype=np.float32) * (0.09 * (512.0 / D) ** 0.5)).astype(np.float32)
     bias = (g.standard_normal(3 * D, dtype=np.float32) * 0.3).astype(np.float32) if with_bias else None
     out = np.zeros((B * L, D), np.uint16)
     ms = C.c_float(0)
@@ -49,7 +51,7 @@ def test_qkv_attention_against_float64_reference(B, extras, with_bias):
     want = _reference(h, w, bias, B, L, H)
     err = np.abs(got - want)
     rows = np.arange(B * L) % L
-    print(f"qkv_attention B={B} extras={extras} bias={with_bias}: max err {err.max():.3e} (patch rows {err[rows >= extras].max():.3e}, "
+    print(f"qkv_attention B={B} H={H} extras={extras} bias={with_bias}: max err {err.max():.3e} (patch rows {err[rows >= extras].max():.3e}, "
           f"extra rows {err[rows < extras].max():.3e}); |out| max {np.abs(want).max():.2f}; {ms.value * 1e3:.1f} us/launch")
     # bf16 output rounding (2^-9 relative) + bf16 P in the P V product + accumulation order
     assert err.max() <= 2e-2 * max(1.0, np.abs(want).max())
