@@ -474,18 +474,19 @@ typedef __attribute__((address_space(3))) void* qa_lptr_t;
 // (counted vmcnt; the old two-slot ring of whole 32 KB tiles was requested one tile ahead and drained with vmcnt(0)), and the bias /
 // pack / LDS-image epilogue runs once, after the last slice.  It is also what lets embed_dim 768 / 1024 in: their rows (192 / 256
 // fragment registers) never fit beside the accumulators at two waves per SIMD.
+// One barrier per block, in its MIDDLE (behind the 8th of its 16 MFMAs): by then every wave has finished block b - 1, so the LDS-DMA of
+// block b + 3 may overwrite that slot, and block b + 1 is confirmed landed half a block before its first fragment is read -- the
+// fragment queue (four ds_read_b128 ahead of their MFMAs) runs on across the block boundaries without a bubble.
 // VMEM bookkeeping (hipcc counts neither the asm loads nor what an LDS-DMA piece covers): every vmcnt below is the exact number of
-// requests issued behind the one waited for (qa_younger_*), from the fixed issue order of a block:
-//   [wait: this block's LDS-DMA pieces] barrier [LDS-DMA of block + 3] [first block of a slice: wait: this slice's rows; request the next slice's]
+// requests issued behind the one waited for, from the fixed issue order of a block:
+//   [first block of a slice: wait: this slice's rows; request the next slice's (8 loads)] 8 MFMAs [wait: LDS-DMA of block + 1] barrier
+//   [LDS-DMA of block + 3 (2 pieces)] [extras' MFMAs] 8 MFMAs
 constexpr int qa_dma_ops(int b, int nb) { return b < nb ? 2 : 0; }                         // LDS-DMA pieces per wave of block b (none past the end)
-constexpr int qa_pref_ops(int b, int nb) { return (b % 3 == 0 && b / 3 + 1 < nb / 3) ? kQaKQ : 0; }   // row requests issued in block b (for the next slice)
-// requests younger than block b's LDS-DMA (issued first thing in block b - 3) when block b waits for it
-constexpr int qa_younger_dma(int b, int nb) {
-    return qa_pref_ops(b - 3, nb) + qa_dma_ops(b + 1, nb) + qa_pref_ops(b - 2, nb) + qa_dma_ops(b + 2, nb) + qa_pref_ops(b - 1, nb);
-}
-// requests younger than the rows of the slice that starts at block b (requested in block b - 3, behind that block's LDS-DMA) when
-// block b, having issued its own LDS-DMA, waits for them
-constexpr int qa_younger_rows(int b, int nb) { return qa_dma_ops(b + 1, nb) + qa_dma_ops(b + 2, nb) + qa_dma_ops(b + 3, nb); }
+constexpr int qa_pref_ops(int b, int nb) { return (b >= 0 && b % 3 == 0 && b / 3 + 1 < nb / 3) ? kQaKQ : 0; }   // row requests issued at the start of block b (for the next slice)
+// requests younger than the LDS-DMA of block b + 1 (issued in the middle of block b - 2) when the middle of block b waits for it
+constexpr int qa_younger_dma(int b, int nb) { return qa_pref_ops(b - 1, nb) + qa_dma_ops(b + 2, nb) + qa_pref_ops(b, nb); }
+// requests younger than the rows of the slice that starts at block b (requested at the start of block b - 3) when block b waits for them
+constexpr int qa_younger_rows(int b, int nb) { return qa_dma_ops(b, nb) + qa_dma_ops(b + 1, nb) + qa_dma_ops(b + 2, nb); }
 
 template <int D>
 __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs a) {
@@ -583,15 +584,13 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     const int xg = lane >> 4, xn = lane & 15;
     const int wx16 = (2 * (wave >> 1) + (xg >> 1)) * 1024 + ((16 * (wave & 1) + xn) + 32 * (xg & 1)) * 16;
     const char* hx16 = hxl + (xn < E ? xn : 0) * (D * 2) + (wave >> 1) * 64 + xg * 16;
+    bf16x8 wq[4];            // the fragment queue: fragment g of the stream (block g >> 4, fragment g & 15) is read four MFMAs ahead
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // blocks 0..2, slice 0 of the rows, hxl, the zero rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(ring + lane * 16 + i * 1024);
     [&]<int... BI>(std::integer_sequence<int, BI...>) {
         ([&] {
             constexpr int bb = BI, q = bb / 3, jj = bb % 3, S = q & 1;
-            // this wave's pieces of block bb have landed (in-order returns; the exact count of younger requests: qa_younger_dma)
-            if constexpr (bb == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (and slice 0 of the rows, hxl, the zero rows)
-            else if constexpr (bb < 3) asm volatile("s_barrier" ::: "memory");                                              // (landed with the wait of block 0)
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(qa_younger_dma(bb, NB)) : "memory");
-            // ... everyone's have, and nobody still reads the slot block bb + 3 goes to (block bb - 1's)
-            if constexpr (bb + 3 < NB) dma_block(bb + 3);
             if constexpr (jj == 0) {
                 if constexpr (q > 0) {      // this slice's rows (requested three blocks ago): one wait, tied to the registers it guards
                     asm volatile("s_waitcnt vmcnt(%8)"
@@ -605,30 +604,35 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
                 }
             }
             const char* wb = ring + (bb & 3) * kQaBlk + lane * 16;
-            // weight fragments four ahead of their MFMAs: fragment f = tile 2 jj + (f >> 3), k-step f & 7 of the slice
-            bf16x8 wq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+            const char* wbn = ring + ((bb + 1) & 3) * kQaBlk + lane * 16;
 #pragma unroll
             for (int f = 0; f < 2 * kQaKQ; ++f) {
+                if (f == kQaKQ) {
+                    if constexpr (bb + 1 < NB) {
+                        // this wave's pieces of block bb + 1 have landed (bb + 1 < 3: with the wait in front of block 0) | everyone's have, and
+                        // everyone is past block bb - 1
+                        if constexpr (bb + 1 >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(qa_younger_dma(bb, NB)) : "memory");
+                        else asm volatile("s_barrier" ::: "memory");
+                    }
+                    if constexpr (bb + 3 < NB) dma_block(bb + 3);
+                    // the extra tokens' rows against this block, on v_mfma_f32_16x16x32_bf16 (M = 16 of the tile's 32 columns, N = 16 "rows" of
+                    // which the first E are the extra tokens, K = 32): wave w takes column half w & 1 and k-block w >> 1 of the slice's four, one
+                    // small MFMA per tile, accumulated over ALL slices in 4 registers per tile -- no LDS round trip per block (the 32x32 form
+                    // with its partial sums read-modify-written in LDS cost 45 % of phase A for 0.4 % of the rows); the waves' partial sums meet
+                    // in LDS once, after the last slice.  The A fragment is gathered from the block's 32x32x16 fragment order, 16 bytes per lane.
+                    const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hx16 + q * (kQaKQ * 32));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(ring + (bb & 3) * kQaBlk + t * (kQaKQ * 1024) + wx16);
+                        accx[2 * jj + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb, accx[2 * jj + t], 0, 0, 0);
+                    }
+                }
                 const bf16x8 w0 = wq[f & 3];
                 if (f + 4 < 2 * kQaKQ) wq[f & 3] = *reinterpret_cast<const bf16x8*>(wb + (f + 4) * 1024);
+                else if (bb + 1 < NB) wq[f & 3] = *reinterpret_cast<const bf16x8*>(wbn + (f + 4 - 2 * kQaKQ) * 1024);   // the next block's first fragments
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2 * jj + (f >> 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xs[S][f & 7], acc[2 * jj + (f >> 3)], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            // the extra tokens' rows against this block, on v_mfma_f32_16x16x32_bf16 (M = 16 of the tile's 32 columns, N = 16 "rows" of which
-            // the first E are the extra tokens, K = 32): wave w takes column half w & 1 and k-block w >> 1 of the slice's four, one small
-            // MFMA per tile, accumulated over ALL slices in 4 registers per tile -- no LDS round trip per block (the 32x32 form with its
-            // partial sums read-modify-written in LDS cost 45 % of phase A for 0.4 % of the rows); the waves' partial sums meet in LDS once,
-            // after the last slice.  The A fragment is gathered from the block's 32x32x16 fragment order with one 16-byte read per lane.
-            {
-                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hx16 + q * (kQaKQ * 32));
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf16x8 wa = *reinterpret_cast<const bf16x8*>(ring + (bb & 3) * kQaBlk + t * (kQaKQ * 1024) + wx16);
-                    accx[2 * jj + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb, accx[2 * jj + t], 0, 0, 0);
-                }
             }
         }(), ...);
     }(std::make_integer_sequence<int, NB>{});
