@@ -12,6 +12,11 @@ mkdir -p $out
 WL="${@:-celeba imagenet64 imagenet256}"
 for W in $WL; do
   sfx=""; [ $W != celeba ] && sfx="_$W"
+  # PMC first: bench.py quotes HBM traffic / MFMA-busy / clock of the dominant kernel from profiles/r04/pmc_*.json when they are of THIS build
+  bash tools/collect_pmc.sh $W $R/gpurun_out/pmc$sfx > $out/pmc$sfx.log 2>&1
+  for f in pmc_traffic.json pmc_sq.json; do cp gpurun_out/pmc$sfx/$f $out/${f%.json}$sfx.json; cp gpurun_out/pmc$sfx/$f $R/profiles/r04/${f%.json}$sfx.json; done
+  cp gpurun_out/pmc$sfx/pmc_traffic_summary.txt $out/pmc_traffic_summary$sfx.txt
+  cp gpurun_out/pmc$sfx/pmc_sq_utilisation.txt $out/pmc_sq_utilisation$sfx.txt
   rm -rf $out/kt$sfx && mkdir -p $out/kt$sfx
   if [ $W = celeba ]; then
     timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_cmd_steps20.json 2> $out/bench_steps20.err
@@ -23,9 +28,5 @@ for W in $WL; do
   python3 tools/prof_summary.py $out/kt$sfx 100 > $out/kernel_trace_summary$sfx.txt
   cp $out/kt$sfx/kt_kernel_stats.csv $out/kernel_stats$sfx.csv
   rm -rf $out/kt$sfx
-  bash tools/collect_pmc.sh $W $R/gpurun_out/pmc$sfx > $out/pmc$sfx.log 2>&1
-  for f in pmc_traffic.json pmc_sq.json; do cp gpurun_out/pmc$sfx/$f $out/${f%.json}$sfx.json; done
-  cp gpurun_out/pmc$sfx/pmc_traffic_summary.txt $out/pmc_traffic_summary$sfx.txt
-  cp gpurun_out/pmc$sfx/pmc_sq_utilisation.txt $out/pmc_sq_utilisation$sfx.txt
   echo "== $W"; head -c 400 $out/bench$( [ $W = celeba ] && echo _driver_cmd_steps20 || echo $sfx ).json; echo; head -12 $out/kernel_trace_summary$sfx.txt
 done
