@@ -69,6 +69,8 @@ struct BlockW {
     const char* mlp_img;     // fused-MLP weight image (mlp_fused.hip) or null
     const float* mlp_b1p;    // fc1 bias in accumulator-register order
     const bf16_t* qa_img;    // attn.qkv weight per head in fragment order (qkv_attention_pack) or null
+    const char* rl_img = nullptr;   // mlp.fc2 weight as the row-resident launch streams it (rowlin_pack) or null
+    const char* rlp_img = nullptr;  // attn.proj weight, ditto
 };
 
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred) or null
@@ -124,6 +126,8 @@ struct dd_model {
     bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
                                           //     whose heads read every block's output)
     bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
+    bool rowlin_proj = false;             // ... and attn.proj + residual + norm2 likewise
+    bool rowlin_fc2 = false;              // embed_dim 768 on the GEMM path: mlp.fc2 + residual + the next block's norm1 in one row-resident launch (rowlin.hip)
     bool fused_qa = false;                // attn.qkv computed inside the attention launch (attention.hip qkv_attention_kernel): takes precedence over
                                           // fused_qkv wherever the previous block's fused launch leaves norm1 in h
     bf16_t* qkv_dump = nullptr;           // scratch for the qkv stores of rows past the end of a ragged tile
@@ -512,11 +516,29 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             DD_HIP(c, hipStreamWaitEvent(s, c->ev_ee_join, 0));
             ee_side = false;
         }
-        if (!(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
+        bool ln2_done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (m->rowlin_proj) {
+                // (embed_dim 768) x += proj(ao) + b and norm2 of the updated rows in one row-resident launch (see mlp.fc2 below)
+                RowLinArgs ra{};
+                ra.A = (const bf16_t*)ao; ra.lda = D; ra.K = D; ra.wimg = w.rlp_img; ra.bias = w.proj_b; ra.xres = m->x;
+                ra.partial = m->mlp_partial; ra.ln_g = w.ln2_g; ra.ln_b = w.ln2_b; ra.h_out = (bf16_t*)h;
+                rowlin_plan(B, m->N, m->extras, L, D, ra);
+                DD_HIP(c, launch_rowlin(ra, s));
+                MlpFusedArgs fr{};
+                fr.b2 = w.proj_b; fr.xres = m->x; fr.partial = m->mlp_partial; fr.ldo = D;
+                fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
+                fr.groups = ra.groups; fr.prows = 128;
+                fr.ln_out_g = w.ln2_g; fr.ln_out_b = w.ln2_b; fr.ln_out = (bf16_t*)h;
+                DD_HIP(c, launch_mlp_reduce(fr, D, s));
+                ln2_done = true;
+            }
+        }
+        if (!ln2_done && !(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
-        if (!(sizeof(T) == 2 && m->fused_mlp)) DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));   // fused MLP: norm2 in its prologue
+        if (!ln2_done && !(sizeof(T) == 2 && m->fused_mlp)) DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));   // fused MLP: norm2 in its prologue
         // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
         // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
         T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
@@ -592,6 +614,31 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             if (timed) if (int rc = mark()) return rc;
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s, c->num_cus));
             if (timed) if (int rc = mark()) return rc;
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (m->rowlin_fc2) {
+                // x += fc2(hid) + b with each wave's 32 residual rows resident in registers; where the next block starts with norm1 (in- and
+                // mid-blocks) that LayerNorm leaves from the same registers -- in the attention launch's fragment order under fused_qa
+                RowLinArgs ra{};
+                ra.A = (const bf16_t*)hid; ra.lda = m->hid_ld; ra.K = m->hidden; ra.wimg = w.rl_img; ra.bias = w.fc2_b; ra.xres = m->x;
+                ra.x_copy = (bf16_t*)copy; ra.partial = m->mlp_partial;
+                const bool ln_next = bi + 1 < nb && bi + 1 <= m->half_depth;
+                if (ln_next) {
+                    ra.ln_g = m->blocks[bi + 1].ln1_g; ra.ln_b = m->blocks[bi + 1].ln1_b;
+                    if (m->fused_qa) ra.h_frag = m->hfrag; else ra.h_out = (bf16_t*)h;
+                }
+                rowlin_plan(B, m->N, m->extras, L, m->hidden, ra);
+                DD_HIP(c, launch_rowlin(ra, s));
+                MlpFusedArgs fr{};           // the extra-token rows: bias + residual + the K-split slabs in a fixed order (+ their norm1 rows)
+                fr.b2 = w.fc2_b; fr.xres = m->x; fr.out = (bf16_t*)copy; fr.ldo = D; fr.partial = m->mlp_partial;
+                fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
+                fr.groups = ra.groups; fr.prows = 128;
+                if (ln_next && !m->fused_qa) { fr.ln_out_g = ra.ln_g; fr.ln_out_b = ra.ln_b; fr.ln_out = (bf16_t*)h; }
+                DD_HIP(c, launch_mlp_reduce(fr, D, s));
+                h_ready = ln_next;
+                qa_ready = ln_next && m->fused_qa;    // (the extra-token rows reach the attention launch through the residual stream x)
+                continue;
+            }
         }
         {
             GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
@@ -783,7 +830,7 @@ int dd_ctx_create(int device, dd_ctx** out) {
               hipEventCreateWithFlags(&c->ev_ee_join, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
-         init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess;
+         init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess && init_rowlin_kernels() == hipSuccess;
     if (!ok) { dd_ctx_destroy(c); return DD_ERR_HIP; }
     *out = c;
     return DD_OK;
@@ -911,8 +958,11 @@ int dd_model_finalize(dd_model* m, int precision) {
     // (early-exit models too: their heads and probes read the residual stream between blocks, which this launch does not touch)
     // (embed_dim 768 / 1024 too, which have no fused block tail: their norm1 launch writes the fragment order, the qkv tensor is gone)
     m->fused_qa = precision == DD_PREC_BF16 && qkv_attention_supported(D, m->H, L, m->extras) && !(c->dev_flags & DD_DEV_NO_FUSED_QA);
+    // (embed_dim 768, no fused block tail) mlp.fc2 with the residual rows resident in registers: x read and written once, the next norm1 from registers
+    m->rowlin_fc2 = precision == DD_PREC_BF16 && !m->fused_mlp && rowlin_supported(D, hid) && m->N % 32 == 0 && !(c->dev_flags & DD_DEV_NO_ROWLIN);
+    m->rowlin_proj = m->rowlin_fc2 && !(c->dev_flags & DD_DEV_NO_ROWLIN_PROJ);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
-    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img; bool skip; };
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img, rl_img, rlp_img; bool skip; };
     std::vector<BlockOff> boffs;
     // next_skip: prefix of the block whose skip_linear runs in THIS block's fused launch ("" = none)
     // next_qkv: prefix of the block whose attn.qkv runs in THIS block's fused launch ("" = none: the last block)
@@ -947,6 +997,12 @@ int dd_model_finalize(dd_model* m, int precision) {
         if (m->fused_qa) {
             o.qa_img = put_raw((size_t)3 * D * D * 2);
             qkv_attention_pack(D, m->H, P(p + "attn.qkv.weight").data(), host_f2bf, (unsigned short*)&host[o.qa_img]);
+        }
+        if (m->rowlin_fc2) {
+            o.rl_img = put_raw((size_t)D * hid * 2);
+            rowlin_pack(hid, P(p + "mlp.fc2.weight").data(), host_f2bf, (unsigned short*)&host[o.rl_img]);
+            o.rlp_img = put_raw((size_t)D * D * 2);
+            rowlin_pack(D, P(p + "attn.proj.weight").data(), host_f2bf, (unsigned short*)&host[o.rlp_img]);
         }
         boffs.push_back(o);
     };
@@ -1072,7 +1128,8 @@ int dd_model_finalize(dd_model* m, int precision) {
         BlockW w{F(o.ln1_g), F(o.ln1_b), F(o.ln2_g), F(o.ln2_b), F(o.proj_b), F(o.fc1_b), F(o.fc2_b),
                  o.skip ? F(o.skip_b) : nullptr, m->cfg.qkv_bias ? F(o.qkv_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
                  o.skip ? V(o.skip_w) : nullptr, m->fused_mlp ? (const char*)V(o.mlp_img) : nullptr,
-                 m->fused_mlp ? F(o.mlp_b1p) : nullptr, m->fused_qa ? (const bf16_t*)V(o.qa_img) : nullptr};
+                 m->fused_mlp ? F(o.mlp_b1p) : nullptr, m->fused_qa ? (const bf16_t*)V(o.qa_img) : nullptr,
+                 m->rowlin_fc2 ? (const char*)V(o.rl_img) : nullptr, m->rowlin_fc2 ? (const char*)V(o.rlp_img) : nullptr};
         m->blocks.push_back(w);
     }
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
@@ -1094,7 +1151,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     std::vector<size_t> o_sk;
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
     const size_t o_dec = take(Mp * m->pd * 4);
-    const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid) : 0;
+    const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid)
+                              : m->rowlin_fc2 ? std::max(rowlin_partial_bytes(m->cfg.max_batch, m->extras, hid), rowlin_partial_bytes(m->cfg.max_batch, m->extras, D)) : 0;
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
     const size_t o_hf = take(m->fused_qa ? (size_t)m->cfg.max_batch * m->N * D * 2 : 0);

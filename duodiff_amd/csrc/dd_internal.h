@@ -150,6 +150,29 @@ hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t launch_mlp_reduce(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t init_mlp_fused_kernels();
 
+// ---- row-resident Linear + bias + residual + LayerNorm for embed_dim 768 (rowlin.hip): x += A . W^T + b ; LayerNorm(x) g + beta as bf16
+struct RowLinArgs {
+    const bf16_t* A;       // [rows, lda] bf16 rows of the Linear's input (k contiguous)
+    int lda, K;            // K % 64 == 0
+    const char* wimg;      // rowlin_pack image of W [768, K]
+    const float* bias;     // [768]
+    float* xres;           // fp32 [rows, 768] residual stream, updated in place
+    const float *ln_g, *ln_b;   // LayerNorm of the updated rows (h_out / h_frag)
+    bf16_t* h_out;         // row-major [rows, 768] bf16, or null
+    bf16_t* h_frag;        // or: the main (patch) rows in MFMA fragment order (MlpFusedArgs::ln_out_frag), or null
+    bf16_t* x_copy;        // optional bf16 copy of the updated rows, row-major
+    float* partial;        // slabs of the K-split extra-token tiles [tiles_extra * groups][128][768] fp32
+    int M;                 // plain mode (tok_n == 0): rows [0, M) in tiles of 128
+    // row plan (rowlin_plan; tok_n > 0): token row of image b, token l = b * tok_l + l; tokens [0, tok_e) are the extras, then tok_n patches
+    int tok_n, tok_e, tok_l, n_main, n_extra, tiles_main, tiles_extra, groups, cpg;
+};
+bool rowlin_supported(int D, int K);
+void rowlin_pack(int K, const float* w, unsigned short (*to_bf16)(float), unsigned short* img);
+void rowlin_plan(int B, int n_patches, int extras, int seq_len, int K, RowLinArgs& a);
+size_t rowlin_partial_bytes(int max_batch, int extras, int K);
+hipError_t launch_rowlin(const RowLinArgs& a, hipStream_t s);
+hipError_t init_rowlin_kernels();
+
 struct EmbedArgs {
     const float* x_img;      // [B,C,S,S]
     const float* wt;         // [pd, D]  patch-embed weight, transposed

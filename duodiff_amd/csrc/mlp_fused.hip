@@ -1564,6 +1564,7 @@ hipError_t launch_mlp_reduce(const MlpFusedArgs& a, int D, hipStream_t s) {
         case 128: return launch_reduce_d<128>(a, s);
         case 256: return launch_reduce_d<256>(a, s);
         case 512: return launch_reduce_d<512>(a, s);
+        case 768: return launch_reduce_d<768>(a, s);     // the K-split extra-token tiles of rowlin.hip
     }
     return hipErrorInvalidValue;
 }

@@ -581,6 +581,36 @@ def test_kernel_variant_flags_agree_with_the_default_path(flags):
     assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
 
 
+@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 1024), (32, 3, 2048), (16, 5, 0), (16, 5, 1024)])
+def test_row_resident_fc2_at_embed_dim_768(img, B, flags):
+    """embed_dim 768 (the ImageNet-64 width) has no fused block tail; its mlp.fc2 + residual + the next block's norm1 run as one
+    row-resident launch (rowlin.hip), the extra-token rows K-split into slabs.  5-block class-conditional models: 256 patches
+    (norm1 leaves in the attention launch's fragment order; flags 128: row-major, the qkv GEMM reads it) and 64 patches at B = 5
+    (a ragged 128-row tile), each against the oracle like the GEMM + LayerNorm pairs it replaces (flags 1024; 2048: attn.proj + norm2 alone stay a GEMM pair)."""
+    from duodiff_amd.engine import Context
+    cfg = dict(img_size=img, patch_size=2, in_chans=3, embed_dim=768, depth=5, num_heads=12, mlp_ratio=4, qkv_bias=False,
+               mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
+    g = torch.Generator().manual_seed(77 + img)
+    x = torch.randn(B, 3, img, img, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    t = torch.full((B,), 420.0)
+    want = _oracle(cfg, 4244)(x.numpy(), t.numpy(), y.numpy())
+    sigma = float(want.std())
+    ctx = Context.get()
+    try:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+        m, _ = _uvit(cfg, 4244, "bf16", max_batch=B)
+        got = m(x, t, y).cpu().numpy()
+        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous()).cpu().numpy()
+        del m
+    finally:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+    err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
+    print(f"D=768 img {img} B={B} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+    assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
+    assert np.array_equal(alone, got[B - 1:])        # the same image computed alone: bit-identical (no batch-dependent split)
+
+
 def test_cli_end_to_end(tmp_path):
     """The sampler CLI with the reference's flags: YAML configs + checkpoint files (bare state_dict and the
     trainer's {"model_state_dict": ...} format) -> statistics.txt and samples, DuoDiff switch included."""
