@@ -430,6 +430,15 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     EmbedArgs ea{x_img, m->emb_wt, m->emb_b, m->pos, m->label, (const long long*)y_dev, t_vec, c->st, m->x,
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, D, L, m->extras,
                  m->cfg.num_classes, m->cfg.normalize_timesteps, Mp, (c->dev_flags & DD_DEV_GENERIC_EMBED) ? 1 : 0};
+    // the first block's norm1 of the patch rows from the embed launch's registers (where the attention launch computes attn.qkv itself and
+    // normalises the extra-token rows from the residual stream: the time_embed MLP below only rewrites such a row)
+    bool ln1_done = false;
+    if constexpr (sizeof(T) == 2) {
+        if (m->fused_qa && !(c->dev_flags & DD_DEV_NO_EMBED_LN) && embed_ln_supported(ea)) {
+            ea.ln_g = m->blocks[0].ln1_g; ea.ln_b = m->blocks[0].ln1_b; ea.ln_frag = m->hfrag;
+            ln1_done = true;
+        }
+    }
     DD_HIP(c, launch_embed(ea, s));
     if (m->tm_w1t) {   // mlp_time_embed: the time token goes through Linear -> SiLU -> Linear (models/uvit.py:264-272, 358)
         TimeMlpArgs ta{m->tm_w1t, m->tm_b1, m->tm_w2t, m->tm_b2, m->pos, t_vec, c->st, m->x, B, D, L, m->extras, m->cfg.normalize_timesteps};
@@ -438,10 +447,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
 
     T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
     const int nb = (int)m->blocks.size();
-    bool h_ready = false;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one)
+    bool h_ready = ln1_done;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one / the embed launch)
     bool skip_done = false; // ... and x already holds that block's skip_linear output (the previous fused launch ran it too)
     bool qkv_done = false;  // ... and qkv already holds that block's attn.qkv output (ditto)
-    bool qa_ready = false;  // ... or only the extra-token rows of it: the patch rows' qkv is computed inside the attention launch
+    bool qa_ready = ln1_done;  // ... or only the extra-token rows of it: the patch rows' qkv is computed inside the attention launch
     bool ee_side = false;   // this block's early-exit head / probe launches are in flight on the side stream
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];

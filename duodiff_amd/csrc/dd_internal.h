@@ -185,7 +185,11 @@ struct EmbedArgs {
     float* x_tok;            // [Mp, D]
     int B, C, S, P, D, L, extras, num_classes, normalize, Mp;
     int generic;             // != 0: the generic VALU kernel even where the MFMA kernel fits (development A/B runs)
+    const float* ln_g = nullptr;   // with ln_frag: the first block's norm1 of the patch rows is written too (embed_ln_supported)
+    const float* ln_b = nullptr;
+    bf16_t* ln_frag = nullptr;     // MFMA fragment order (launch_layernorm_frag's `frag`)
 };
+bool embed_ln_supported(const EmbedArgs& a);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 
 // time_embed MLP (models/uvit.py:264-272): time token = W2 . SiLU(W1 . sinusoid(t) + b1) + b2 (+ pos_embed), fp32, one

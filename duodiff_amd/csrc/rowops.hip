@@ -3,6 +3,8 @@
 // All arithmetic here is fp32 in both precision modes.
 #include "dd_internal.h"
 
+#include <utility>
+
 #include <cstdlib>
 
 namespace dd {
@@ -101,7 +103,10 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedArgs a) {
 // The extra tokens (time sinusoid, label embedding) of an image are written by the workgroup that owns its first patch rows,
 // one column per thread.
 // ------------------------------------------------------------------------------------------
-template <int P, int C>
+// LND > 0 (= embed_dim, compile time): the wave also writes the first block's norm1 of its 16 tokens -- in the MFMA fragment order the attention
+// launch loads (layernorm_kernel's `frag`) -- from the embedded rows it still holds in registers: two-pass statistics over the four lanes
+// of a token, no LayerNorm launch, no second read of x.
+template <int P, int C, int LND = 0>
 __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
     constexpr int PD = P * P * C, KK = PD / 4, KK4 = (KK + 3) / 4;
     static_assert(PD % 4 == 0, "k-steps of 4");
@@ -178,15 +183,59 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
             }
             // lane (n, kq) holds columns 32 p + 4 kq + {0..3} (even tile) and 32 p + 16 + 4 kq + {0..3} (odd tile) of token n:
             // the four lanes of a token write 64 contiguous bytes per store, the two stores one 128-byte line
-            *reinterpret_cast<f32x4*>(xrow + 32 * pp) = (acc_e + q.be) + q.pe;
-            *reinterpret_cast<f32x4*>(xrow + 32 * pp + 16) = (acc_o + q.bo) + q.po;
+            const f32x4 ve = (acc_e + q.be) + q.pe, vo = (acc_o + q.bo) + q.po;
+            *reinterpret_cast<f32x4*>(xrow + 32 * pp) = ve;
+            *reinterpret_cast<f32x4*>(xrow + 32 * pp + 16) = vo;
+            return std::pair<f32x4, f32x4>{ve, vo};
         };
         Quads qa = fetch(0), qb = qa;
-        for (int p = 0; p < NP; p += 2) {        // (NP = D / 32 is even: D is a multiple of 64)
-            qb = fetch(p + 1);
-            pair(p, qa);
-            qa = fetch(p + 2 < NP ? p + 2 : p + 1);
-            pair(p + 1, qb);
+        if constexpr (LND > 0) {
+            constexpr int NPC = LND / 32;
+            f32x4 keep[2 * NPC];                  // the token's columns 16 t + 4 kq .. + 3, t = 0 .. D / 16 - 1
+#pragma unroll
+            for (int p = 0; p < NPC; p += 2) {
+                qb = fetch(p + 1);
+                const auto r0 = pair(p, qa);
+                keep[2 * p] = r0.first; keep[2 * p + 1] = r0.second;
+                qa = fetch(p + 2 < NPC ? p + 2 : p + 1);
+                const auto r1 = pair(p + 1, qb);
+                keep[2 * p + 2] = r1.first; keep[2 * p + 3] = r1.second;
+            }
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2 * NPC; ++t) s4 += keep[t];
+            float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)LND;
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2 * NPC; ++t) { const f32x4 d = keep[t] - mean; q4 += d * d; }
+            float q2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            q2 += __shfl_xor(q2, 16);
+            q2 += __shfl_xor(q2, 32);
+            const float rstd = 1.0f / sqrtf(q2 / (float)LND + 1e-5f);
+            // fragment order: [32-row group of patch rows][k-step][64 lanes] x 16 bytes; columns 16 t + 4 kq .. + 3 of the token = k-step t,
+            // lane (row in group) + 32 (kq >> 1), elements 4 (kq & 1) .. + 3
+            const long long grp = (long long)b * 8 + (gy >> 1);
+            bf16_t* frow = a.ln_frag + ((grp * (LND / 16)) * 64 + ((gy & 1) * 16 + n) + 32 * (kq >> 1)) * 8 + 4 * (kq & 1);
+            const float* gr = a.ln_g + 4 * kq;
+            const float* br = a.ln_b + 4 * kq;
+#pragma unroll
+            for (int t = 0; t < 2 * NPC; ++t) {
+                const f32x4 gq = *reinterpret_cast<const f32x4*>(gr + 16 * t), bq = *reinterpret_cast<const f32x4*>(br + 16 * t);
+                bf16_t o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = f2bf((keep[t][e] - mean) * rstd * gq[e] + bq[e]);
+                *reinterpret_cast<uint2*>(frow + (long long)t * 512) = *reinterpret_cast<const uint2*>(o4);
+            }
+        } else {
+            for (int p = 0; p < NP; p += 2) {        // (NP = D / 32 is even: D is a multiple of 64)
+                qb = fetch(p + 1);
+                pair(p, qa);
+                qa = fetch(p + 2 < NP ? p + 2 : p + 1);
+                pair(p + 1, qb);
+            }
         }
     }
     if (((blockIdx.x * 8) & 15) == 0 && (int)(blockIdx.x * 8) / 16 < a.B) {   // the image's extra tokens: [label,] time (reference models/uvit.py:356-365)
@@ -768,10 +817,21 @@ bool embed_mfma_ok(const EmbedArgs& a, size_t& lds) {
            ((a.P == 4 && a.C == 3) || (a.P == 2 && a.C == 3) || (a.P == 2 && a.C == 4));
 }
 
+// the MFMA kernel's variant that also writes the first block's norm1 in fragment order: the CelebA shape (patch 4, 3 channels, embed_dim 512)
+bool embed_ln_supported(const EmbedArgs& a) {
+    size_t lds = 0;
+    return !a.generic && embed_mfma_ok(a, lds) && a.P == 4 && a.C == 3 && a.D == 512;
+}
+
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     size_t mlds = 0;
     if (!a.generic && embed_mfma_ok(a, mlds)) {
         const dim3 grid((unsigned)((a.B * 16 + 7) / 8));
+        if (a.ln_frag) {      // + the first block's norm1 (embed_ln_supported)
+            if (!embed_ln_supported(a) || !a.ln_g || !a.ln_b) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((embed_mfma_kernel<4, 3, 512>), grid, dim3(512), mlds, s, a);
+            return hipGetLastError();
+        }
         if (a.P == 4) hipLaunchKernelGGL((embed_mfma_kernel<4, 3>), grid, dim3(512), mlds, s, a);
         else if (a.C == 3) hipLaunchKernelGGL((embed_mfma_kernel<2, 3>), grid, dim3(512), mlds, s, a);
         else hipLaunchKernelGGL((embed_mfma_kernel<2, 4>), grid, dim3(512), mlds, s, a);
