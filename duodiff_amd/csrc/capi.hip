@@ -126,6 +126,7 @@ struct dd_model {
     bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
                                           //     whose heads read every block's output)
     bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
+    bool splitk = false;                  // GEMM-path models whose N = embed_dim Linears have too few 256 x 256 tiles at max_batch: split-K + reduce_ln launches
     bool rowlin_proj = false;             // ... and attn.proj + residual + norm2 likewise
     bool rowlin_fc2 = false;              // embed_dim 768 on the GEMM path: mlp.fc2 + residual + the next block's norm1 in one row-resident launch (rowlin.hip)
     bool fused_qa = false;                // attn.qkv computed inside the attention launch (attention.hip qkv_attention_kernel): takes precedence over
@@ -495,7 +496,18 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             const int oi = bi - m->half_depth - 1;
             const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
-            DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
+            bool done = false;
+            if constexpr (sizeof(T) == 2) {
+                if (m->splitk) {     // split-K halves -> slabs; x = bias + slabs and this block's norm1 in the row pass behind it
+                    g.partial = m->mlp_partial; g.splits = 2;
+                    DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                    ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 0, w.skip_b, nullptr, D, w.ln1_g, w.ln1_b, (bf16_t*)h,
+                                    m->fused_qa ? m->hfrag : nullptr, L, m->extras, M};
+                    DD_HIP(c, launch_reduce_ln(ra, D, s));
+                    h_ready = true; qa_ready = m->fused_qa; done = true;
+                }
+            }
+            if (!done) DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_SET, s, c->num_cus));
         }
         skip_done = false;
         if (!h_ready && !qkv_done) {     // else: written by the previous block's fused MLP
@@ -540,6 +552,16 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 fr.groups = ra.groups; fr.prows = 128;
                 fr.ln_out_g = w.ln2_g; fr.ln_out_b = w.ln2_b; fr.ln_out = (bf16_t*)h;
                 DD_HIP(c, launch_mlp_reduce(fr, D, s));
+                ln2_done = true;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (m->splitk && !ln2_done) {     // attn.proj as split-K halves; x += bias + slabs and norm2 in the row pass behind it
+                GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, nullptr, nullptr, nullptr, M, D, D, D, D, 0, D};
+                g.partial = m->mlp_partial; g.splits = 2;
+                DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 1, w.proj_b, nullptr, D, w.ln2_g, w.ln2_b, (bf16_t*)h, nullptr, L, m->extras, M};
+                DD_HIP(c, launch_reduce_ln(ra, D, s));
                 ln2_done = true;
             }
         }
@@ -646,6 +668,21 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, launch_mlp_reduce(fr, D, s));
                 h_ready = ln_next;
                 qa_ready = ln_next && m->fused_qa;    // (the extra-token rows reach the attention launch through the residual stream x)
+                continue;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (m->splitk) {     // mlp.fc2 as split-K halves; x += bias + slabs, the bf16 copy and (in- / mid-blocks) the next block's norm1 in the row pass
+                GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, nullptr, nullptr, nullptr, M, D, m->hidden, m->hidden, m->hid_ld, m->hid_ld, D};
+                g.partial = m->mlp_partial; g.splits = 2;
+                DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                const bool ln_next = bi + 1 < nb && bi + 1 <= m->half_depth;
+                ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 1, w.fc2_b, (bf16_t*)copy, D,
+                                ln_next ? m->blocks[bi + 1].ln1_g : nullptr, ln_next ? m->blocks[bi + 1].ln1_b : nullptr, (bf16_t*)h,
+                                ln_next && m->fused_qa ? m->hfrag : nullptr, L, m->extras, M};
+                DD_HIP(c, launch_reduce_ln(ra, D, s));
+                h_ready = ln_next;
+                qa_ready = ln_next && m->fused_qa;
                 continue;
             }
         }
@@ -970,6 +1007,13 @@ int dd_model_finalize(dd_model* m, int precision) {
     // (embed_dim 768, no fused block tail) mlp.fc2 with the residual rows resident in registers: x read and written once, the next norm1 from registers
     m->rowlin_fc2 = precision == DD_PREC_BF16 && !m->fused_mlp && rowlin_supported(D, hid) && m->N % 32 == 0 && !(c->dev_flags & DD_DEV_NO_ROWLIN);
     m->rowlin_proj = m->rowlin_fc2 && !(c->dev_flags & DD_DEV_NO_ROWLIN_PROJ);
+    // split-K for the N = embed_dim Linears (skip_linear, attn.proj, mlp.fc2) where even max_batch leaves half of the CUs without a 256 x 256
+    // tile (ImageNet-256 latents: 32 x 4 tiles): a function of the model (max_batch), never of a call's batch
+    m->splitk = precision == DD_PREC_BF16 && !m->fused_mlp && !m->rowlin_fc2 && D % 256 == 0 && !(c->dev_flags & DD_DEV_NO_SPLITK) &&
+                (long long)(m->cfg.max_batch * L / 256) * (D / 256) * 2 <= device_num_cus() &&
+                (hid / 64) % 2 == 0;
+    for (int b = 1; m->splitk && b <= m->cfg.max_batch; ++b)     // every batch this model can be called with must fit the kernel's row partition
+        m->splitk = gemm_splitk_supported(b * L, D, D, D, 2);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
     struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img, rl_img, rlp_img; bool skip; };
     std::vector<BlockOff> boffs;
@@ -1161,6 +1205,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
     const size_t o_dec = take(Mp * m->pd * 4);
     const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid)
+                              : m->splitk ? (size_t)2 * m->Mp_max * D * 4
                               : m->rowlin_fc2 ? std::max(rowlin_partial_bytes(m->cfg.max_batch, m->extras, hid), rowlin_partial_bytes(m->cfg.max_batch, m->extras, D)) : 0;
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);

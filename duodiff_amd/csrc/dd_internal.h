@@ -58,7 +58,8 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 1,    // out = T(gelu_erf(acc + bias))                 (fc1)
     EPI_BIAS_RESID = 2,   // x += acc + bias ; optional out = T(x)         (proj, fc2)
     EPI_BIAS_SET = 3,     // x  = acc + bias                               (skip_linear)
-    EPI_BIAS_STORE = 4    // out = T(acc + bias)                           (VAE attention q/k projections)
+    EPI_BIAS_STORE = 4,   // out = T(acc + bias)                           (VAE attention q/k projections)
+    EPI_PARTIAL = 5       // partial[split] = acc over the split's k range (launch_gemm_splitk; launch_reduce_ln finishes the Linear)
 };
 
 // Head-major output map of the qkv Linear (what attention.hip reads): element (row m = b * L + l, column c) of the [M, 3D]
@@ -90,11 +91,15 @@ struct GemmArgs {
     int M, N, K, K1;
     int lda, lda2, ldo;
     HeadMajor hm;      // hm.L != 0: `out` is written head-major (the qkv Linear); N % 64 == 0
+    float* partial = nullptr;   // launch_gemm_splitk: fp32 slabs [splits][M][N]
+    int splits = 0;
 };
 
 // num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
 template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int num_cus);
 bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e);
+bool gemm_splitk_supported(int M, int N, int K, int K1, int splits);
+hipError_t launch_gemm_splitk(const GemmArgs<bf16_t>& a, hipStream_t s, int num_cus);
 int device_num_cus();
 
 // ---- fused MLP (mlp_fused.hip): x += fc2(gelu(fc1(h) + b1)) + b2 in one launch
@@ -190,6 +195,23 @@ struct EmbedArgs {
     bf16_t* ln_frag = nullptr;     // MFMA fragment order (launch_layernorm_frag's `frag`)
 };
 bool embed_ln_supported(const EmbedArgs& a);
+
+// finishes a split-K Linear (launch_gemm_splitk) and runs the LayerNorm behind it: rowops.hip reduce_ln_kernel
+struct ReduceLnArgs {
+    float* x;               // fp32 [rows, D] residual stream (read when resid != 0, written always)
+    const float* partial;   // fp32 slabs [splits][slab elements], row-major [rows, D] each
+    long long slab;         // elements per slab (the GEMM's M * N)
+    int splits, resid;
+    const float* bias;      // [D]
+    bf16_t* copy;           // optional bf16 copy of the updated rows, row stride ldo
+    int ldo;
+    const float *ln_g, *ln_b;   // optional LayerNorm of the updated rows ...
+    bf16_t* h;              // ... row-major [rows, D] (with frag: only the extra-token rows go here)
+    bf16_t* frag;           // ... or: the patch rows in MFMA fragment order (launch_layernorm_frag's `frag`)
+    int tok_l, tok_e;
+    int rows;
+};
+hipError_t launch_reduce_ln(const ReduceLnArgs& a, int D, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 
 // time_embed MLP (models/uvit.py:264-272): time token = W2 . SiLU(W1 . sinusoid(t) + b1) + b2 (+ pos_embed), fp32, one

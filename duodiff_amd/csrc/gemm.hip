@@ -337,6 +337,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     constexpr int TM = 4, TN = 2;
     constexpr int A_BYTES = k256ARows * 128;
     constexpr int N_EPI_STORES = (EPI == EPI_STORE || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_STORE) ? TM * 4 : TM * TN * 4;
+    constexpr bool PARTIAL = EPI == EPI_PARTIAL;     // split-K: a work item = (tile, k range); the fp32 accumulators go to the split's slab as they are
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -345,7 +346,9 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
     const int h = lane >> 5, r32 = lane & 31;
 
     const int n_tiles = a.N >> 8;
-    const int total = part.q * n_tiles;
+    const int tiles_mn = part.q * n_tiles;
+    const int S = PARTIAL ? a.splits : 1;
+    const int total = tiles_mn * S;
     const int G = gridDim.x, gx = G >> 3, xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;  // G % 8 == 0
     auto tile_of = [&](int i) { return (i * 8 + xcd) * gx + wx; };
     int n_my = 0;
@@ -370,7 +373,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         const unsigned voff_a = lr * (unsigned)sa1 + swz;
         const unsigned voff_w = lr * (unsigned)sw + swz;
         char* at = smem + buf * k256Stage;
-        if (kt == 0 && wave == 1 && EPI != EPI_STORE && a.bias)   // this tile's 256 bias values -> LDS
+        if (kt == 0 && wave == 1 && EPI != EPI_STORE && !PARTIAL && a.bias)   // this tile's 256 bias values -> LDS
             glds16(a.bias + tn * 256 + lane * 4, at - buf * k256Stage + k256BiasOff + parity * 1024);
         const char* Ab = kt < nk1 ? reinterpret_cast<const char*>(a.A) + (long long)kt * 128
                                   : reinterpret_cast<const char*>(a.A2) + (long long)(kt - nk1) * 128;
@@ -488,13 +491,14 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         const bf16v4 b = __builtin_convertvector(q, bf16v4);
         return __builtin_bit_cast(uint2, b);
     };
-    constexpr bool HAS_BIAS = EPI != EPI_STORE;
+    constexpr bool HAS_BIAS = EPI != EPI_STORE && !PARTIAL;
     constexpr bool RESID = EPI == EPI_BIAS_RESID;
     constexpr bool WRITES_X = EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_SET;
 
-    auto epilogue = [&](int lin, int parity) {
+    auto epilogue = [&](int lin, int parity, int sp) {
         const int tm = lin / n_tiles, tn = lin - tm * n_tiles;
-        const bool use_out = EPI != EPI_BIAS_SET && a.out != nullptr;
+        float* const xbase = PARTIAL ? a.partial + (long long)sp * a.M * a.N : a.xres;     // (split-K: this split's [M, N] slab)
+        const bool use_out = EPI != EPI_BIAS_SET && !PARTIAL && a.out != nullptr;
         const bool has_bias = HAS_BIAS && a.bias != nullptr;
         const int col0 = tn * 256 + wc * 64;
         const unsigned bias_lds = lds_addr(smem + k256BiasOff + parity * 1024) + (wc * 64 + 4 * h) * 4;
@@ -505,7 +509,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         };
         const long long row_base = (long long)tm * 256 + wr * 128 + r32;
         auto xptr = [&](int i, int j, int g) {
-            return reinterpret_cast<f32x4*>(a.xres + (row_base + i * 32) * a.N + col0 + j * 32 + 8 * g + 4 * h);
+            return reinterpret_cast<f32x4*>(xbase + (row_base + i * 32) * a.N + col0 + j * 32 + 8 * g + 4 * h);
         };
         f32x4 xl[2][4];   // residual quads of unit u = 2*i + j, double-buffered
         if (RESID) {
@@ -530,8 +534,8 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                     if (HAS_BIAS) q += bias[g];
                     if (EPI == EPI_BIAS_GELU) q = gelu_erf4<T>(q);
                     if (RESID) q = xl[u & 1][g] + q;
-                    if (WRITES_X) *xptr(i, j, g) = q;
-                    v[j][g] = pack4(q);
+                    if (WRITES_X || PARTIAL) *xptr(i, j, g) = q;
+                    if (!PARTIAL) v[j][g] = pack4(q);
                 }
             }
             if (use_out) {
@@ -567,8 +571,8 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                     f32x4 q = {accx[4 * g], accx[4 * g + 1], accx[4 * g + 2], accx[4 * g + 3]};
                     if (HAS_BIAS) q += bias[g];
                     if (EPI == EPI_BIAS_GELU) q = gelu_erf4<T>(q);
-                    if (WRITES_X) {
-                        f32x4* xp = reinterpret_cast<f32x4*>(a.xres + row * a.N + col);
+                    if (WRITES_X || PARTIAL) {
+                        f32x4* xp = reinterpret_cast<f32x4*>(xbase + row * a.N + col);
                         if (RESID) q = *xp + q;
                         *xp = q;
                     }
@@ -581,18 +585,25 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
         }
     };
 
-    int lin = tile_of(0);
-    int tm = lin / n_tiles, tn = lin - tm * n_tiles;
-    stage(tm, tn, 0, 0, 0);
+    // work item i of this workgroup: tile (tm, tn) = lin, k-tiles [kb, ke) (the whole k range unless split-K)
+    struct Item { int lin, tm, tn, sp, kb, ke; };
+    auto item_of = [&](int i) {
+        const int it = tile_of(i);
+        Item w;
+        w.sp = it / tiles_mn;
+        w.lin = it - w.sp * tiles_mn;
+        w.tm = w.lin / n_tiles;
+        w.tn = w.lin - w.tm * n_tiles;
+        w.kb = w.sp * nk / S;
+        w.ke = (w.sp + 1) * nk / S;
+        return w;
+    };
+    Item cur = item_of(0), nxt = cur;
+    stage(cur.tm, cur.tn, cur.kb, 0, 0);
     int buf = 0;
     bool stores_in_flight = false;
     for (int i = 0; i < n_my; ++i) {
-        int lin_next = 0, tm_next = 0, tn_next = 0;
-        if (i + 1 < n_my) {
-            lin_next = tile_of(i + 1);
-            tm_next = lin_next / n_tiles;
-            tn_next = lin_next - tm_next * n_tiles;
-        }
+        if (i + 1 < n_my) nxt = item_of(i + 1);
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
@@ -601,20 +612,20 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
                 for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) accx[e] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = cur.kb; kt < cur.ke; ++kt) {
             // the k-tile about to be read must have landed; only an epilogue's stores may be younger
-            if (kt == 0 && stores_in_flight) wait_vmcnt<N_EPI_STORES>();
+            if (kt == cur.kb && stores_in_flight) wait_vmcnt<N_EPI_STORES>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             compute(buf, [&]() {
-                if (kt + 1 < nk) stage(tm, tn, kt + 1, buf ^ 1, i & 1);
-                else if (i + 1 < n_my) stage(tm_next, tn_next, 0, buf ^ 1, (i + 1) & 1);
+                if (kt + 1 < cur.ke) stage(cur.tm, cur.tn, kt + 1, buf ^ 1, i & 1);
+                else if (i + 1 < n_my) stage(nxt.tm, nxt.tn, nxt.kb, buf ^ 1, (i + 1) & 1);
             });
             buf ^= 1;
         }
-        epilogue(lin, i & 1);
+        epilogue(cur.lin, i & 1, cur.sp);
         stores_in_flight = true;
-        lin = lin_next; tm = tm_next; tn = tn_next;
+        cur = nxt;
     }
 }
 
@@ -678,7 +689,7 @@ bool plan256(int M, int N, int K, int K1, int num_cus, Part256& p) {
 }
 
 hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, int num_cus, hipStream_t s) {
-    const int tiles = p.q * (a.N / 256);
+    const int tiles = p.q * (a.N / 256) * (epi == EPI_PARTIAL ? a.splits : 1);
     int grid = num_cus;                             // a multiple of 8: the kernel groups workgroups by XCD (gx = G >> 3)
     if (tiles < grid) grid = (tiles + 7) / 8 * 8;
 #define DD_LAUNCH(E)                                                                                  \
@@ -692,6 +703,7 @@ hipError_t launch_256(const GemmArgs<bf16_t>& a, int epi, const Part256& p, int 
         case EPI_BIAS_RESID: DD_LAUNCH(EPI_BIAS_RESID)
         case EPI_BIAS_SET: DD_LAUNCH(EPI_BIAS_SET)
         case EPI_BIAS_STORE: DD_LAUNCH(EPI_BIAS_STORE)
+        case EPI_PARTIAL: DD_LAUNCH(EPI_PARTIAL)
     }
 #undef DD_LAUNCH
     return hipErrorInvalidValue;
@@ -708,7 +720,7 @@ hipError_t init_gemm_kernels() {
 #define DD_ATTR(E)                                                                                  \
     if (e == hipSuccess)                                                                            \
         e = hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, k256Lds);
-    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE)
+    DD_ATTR(EPI_STORE) DD_ATTR(EPI_BIAS_GELU) DD_ATTR(EPI_BIAS_RESID) DD_ATTR(EPI_BIAS_SET) DD_ATTR(EPI_BIAS_STORE) DD_ATTR(EPI_PARTIAL)
 #undef DD_ATTR
     return e;
 }
@@ -727,6 +739,23 @@ bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e) {
     const bool ok = plan256(M, N, K, K, num_cus >= 8 ? num_cus / 8 * 8 : 256, p);
     if (ok) { *q = p.q; *e = p.e; }
     return ok;
+}
+
+// Split-K form of the 256 x 256 kernel for Linears with few output tiles (embed_dim-wide outputs at small batches: 32 x 4 tiles at
+// ImageNet-256 latents, B = 32): a work item = (tile, one of a.splits equal k ranges), its fp32 accumulators are stored as they are to
+// slab a.partial[split][M][N]; launch_reduce_ln adds the slabs in ascending split order (+ bias, residual, LayerNorm).  The split is a
+// function of the Linear's shape alone, never of the batch.
+bool gemm_splitk_supported(int M, int N, int K, int K1, int splits) {
+    Part256 p;
+    return splits >= 2 && (K / 64) % splits == 0 && plan256(M, N, K, K1, 256, p);
+}
+hipError_t launch_gemm_splitk(const GemmArgs<bf16_t>& a, hipStream_t s, int num_cus) {
+    Part256 p;
+    const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
+    if (!a.partial || a.hm.L || !gemm_splitk_supported(a.M, a.N, a.K, a.K1, a.splits) || (a.K1 != a.K && (a.lda != a.lda2 || !a.A2)) ||
+        !plan256(a.M, a.N, a.K, a.K1, cus, p))
+        return hipErrorInvalidValue;
+    return launch_256(a, EPI_PARTIAL, p, cus, s);
 }
 
 // bf16: the persistent 256x256 kernel where the shape fits it, else the generic 128x128 kernel; fp32 (parity mode, exact

@@ -387,6 +387,81 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Second half of a split-K Linear (launch_gemm_splitk) and the LayerNorm behind it in one row pass: one wave per token row,
+//   acc = ((p_0 + p_1) + ...) + bias   (ascending split order);   x = resid ? x + acc : acc;   [bf16 copy of x];   [LayerNorm(x) g + b]
+// The LayerNorm launch that followed the Linear read x anyway; here it reads the slabs too and the GEMM's own epilogue is gone.
+// Two-pass statistics and output orders (row-major / fragment order for the patch rows) as layernorm_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NQ>      // D = 256 NQ
+__global__ void __launch_bounds__(256) reduce_ln_kernel(const ReduceLnArgs a) {
+    constexpr int D = 256 * NQ;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    float* xr = a.x + (long long)row * D + lane * 4;
+    f32x4 v[NQ], pv[NQ], bq[NQ], xv[NQ];
+    const float* pr = a.partial + (long long)row * D + lane * 4;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j] = *reinterpret_cast<const f32x4*>(pr + 256 * j);
+        bq[j] = *reinterpret_cast<const f32x4*>(a.bias + 256 * j + lane * 4);
+        if (a.resid) xv[j] = *reinterpret_cast<const f32x4*>(xr + 256 * j);
+    }
+    for (int sp = 1; sp < a.splits; ++sp) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) pv[j] = *reinterpret_cast<const f32x4*>(pr + (long long)sp * a.slab + 256 * j);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) v[j] += pv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j] += bq[j];
+        if (a.resid) v[j] = xv[j] + v[j];
+        *reinterpret_cast<f32x4*>(xr + 256 * j) = v[j];
+    }
+    if (a.copy) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            bf16_t o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = f2bf(v[j][e]);
+            *reinterpret_cast<uint2*>(a.copy + (long long)row * a.ldo + 256 * j + lane * 4) = *reinterpret_cast<const uint2*>(o4);
+        }
+    }
+    if (!a.ln_g) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(sum) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + 1e-5f);
+    bf16_t* orow = a.h + (long long)row * D;
+    bool to_frag = false;
+    if (a.frag) {
+        const int b = row / a.tok_l, l = row - b * a.tok_l;
+        if (l >= a.tok_e) {
+            const int n = l - a.tok_e, grp = b * ((a.tok_l - a.tok_e) / 32) + n / 32;
+            orow = a.frag + ((long long)grp * (D / 16) * 64 + (n & 31)) * 8;
+            to_frag = true;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int c0 = 256 * j + lane * 4;
+        const f32x4 gq = *reinterpret_cast<const f32x4*>(a.ln_g + c0), lb = *reinterpret_cast<const f32x4*>(a.ln_b + c0);
+        bf16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = f2bf((v[j][e] - mean) * rstd * gq[e] + lb[e]);
+        const long long off = to_frag ? ((long long)(c0 >> 4) * 64 + 32 * ((c0 >> 3) & 1)) * 8 + (c0 & 7) : c0;
+        *reinterpret_cast<uint2*>(orow + off) = *reinterpret_cast<const uint2*>(o4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Device noise: Philox4x32-10 counter RNG + Box-Muller.  Counter = (element/4, t, 0, 0),
 // key = seed.  Statistically N(0,1); NOT the torch CPU mt19937 stream (that is DD_NOISE_BUFFER).
 // ------------------------------------------------------------------------------------------
@@ -861,6 +936,19 @@ hipError_t launch_layernorm_frag(const float* x, const float* gamma, const float
                                  int tok_l, int tok_e, hipStream_t s) {
     if (D % 256 || D > 64 * kLnMaxPerLane || !frag || tok_l <= tok_e || (tok_l - tok_e) % 32 || rows % tok_l) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, D, frag, tok_l, tok_e);
+    return hipGetLastError();
+}
+hipError_t launch_reduce_ln(const ReduceLnArgs& a, int D, hipStream_t s) {
+    if (D % 256 || D > 1024 || a.rows < 1 || a.splits < 1 || !a.x || !a.partial || !a.bias || (a.ln_g && (!a.ln_b || !a.h)) ||
+        (a.frag && (a.tok_l <= a.tok_e || (a.tok_l - a.tok_e) % 32 || a.rows % a.tok_l)))
+        return hipErrorInvalidValue;
+    const dim3 grid((a.rows + 3) / 4);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(reduce_ln_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(reduce_ln_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(reduce_ln_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(reduce_ln_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 template hipError_t launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);

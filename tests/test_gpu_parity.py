@@ -611,6 +611,37 @@ def test_row_resident_fc2_at_embed_dim_768(img, B, flags):
     assert np.array_equal(alone, got[B - 1:])        # the same image computed alone: bit-identical (no batch-dependent split)
 
 
+@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 8192), (16, 5, 0)])
+def test_split_k_linears_at_embed_dim_1024(img, B, flags):
+    """embed_dim 1024 at small batches (the ImageNet-256 latent models): skip_linear, attn.proj and mlp.fc2 run as split-K halves of the
+    256 x 256 kernel + one row pass (slabs + bias + residual + the LayerNorm behind the Linear).  5-block class-conditional models
+    against the oracle, like the whole-K GEMM + LayerNorm launches they replace (flags 8192); flags 128: norm1 row-major for the
+    qkv GEMM; 64 patches: sequence lengths the 256 x 256 row partition does not take keep the whole-K launches.  The same image
+    computed alone is bit-identical."""
+    from duodiff_amd.engine import Context
+    cfg = dict(img_size=img, patch_size=2, in_chans=4, embed_dim=1024, depth=5, num_heads=16, mlp_ratio=4, qkv_bias=False,
+               mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
+    g = torch.Generator().manual_seed(78 + img)
+    x = torch.randn(B, 4, img, img, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    t = torch.full((B,), 130.0)
+    want = _oracle(cfg, 4245)(x.numpy(), t.numpy(), y.numpy())
+    sigma = float(want.std())
+    ctx = Context.get()
+    try:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+        m, _ = _uvit(cfg, 4245, "bf16", max_batch=B)
+        got = m(x, t, y).cpu().numpy()
+        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous()).cpu().numpy()
+        del m
+    finally:
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+    err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
+    print(f"D=1024 img {img} B={B} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+    assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
+    assert np.array_equal(alone, got[B - 1:])
+
+
 def test_cli_end_to_end(tmp_path):
     """The sampler CLI with the reference's flags: YAML configs + checkpoint files (bare state_dict and the
     trainer's {"model_state_dict": ...} format) -> statistics.txt and samples, DuoDiff switch included."""
