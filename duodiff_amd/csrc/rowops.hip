@@ -114,6 +114,9 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
     f32x4* wl = reinterpret_cast<f32x4*>(emb_lds);            // [D / 32][2][KK4][64 lanes] x 4 k-steps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int D = a.D, S = a.S, NP = D / 32;
+    // gridDim.y > 1 (few images: ImageNet-256 latents at B = 32 are 64 workgroups): the column pairs are dealt over blockIdx.y, each
+    // workgroup parks and multiplies only its share of the weight image (same arithmetic per element)
+    const int NPY = NP / (int)gridDim.y, p0 = (int)blockIdx.y * NPY;
     const int pass = blockIdx.x * 8 + wave, b = pass >> 4, gy = pass & 15;
     const bool valid = b < a.B;
     if (blockIdx.x == 0 && tid == 0) a.st->t_final = a.st->t;   // handed to the step's last kernel (StepState)
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
     }
     // A operand image -> LDS, all loads of a thread before its first write
     {
-        const int items = NP * 2 * KK4 * 64;
+        const int items = NPY * 2 * KK4 * 64;
         constexpr int MAXI = 16;                               // items per thread: D = 1024, PD = 16 -> 8; D = 768, PD = 48 -> 18 (two rounds)
         for (int base = 0; base < items; base += 512 * MAXI) {
             f32x4 v[MAXI];
@@ -137,7 +140,7 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
                 v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (item < items) {
                     const int l = item & 63, kk4 = (item >> 6) % KK4, ph = (item >> 6) / KK4;   // ph = 2 p + half
-                    const int col = 16 * ph + (l & 15);
+                    const int col = 16 * (ph + 2 * p0) + (l & 15);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int kk = 4 * kk4 + j;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
             f32x4 acc_e = {0.f, 0.f, 0.f, 0.f}, acc_o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk4 = 0; kk4 < KK4; ++kk4) {
-                const f32x4 we = wlp[((2 * pp) * KK4 + kk4) * 64], wo = wlp[((2 * pp + 1) * KK4 + kk4) * 64];
+                const f32x4 we = wlp[((2 * (pp - p0)) * KK4 + kk4) * 64], wo = wlp[((2 * (pp - p0) + 1) * KK4 + kk4) * 64];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (4 * kk4 + j < KK) {
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
             *reinterpret_cast<f32x4*>(xrow + 32 * pp + 16) = vo;
             return std::pair<f32x4, f32x4>{ve, vo};
         };
-        Quads qa = fetch(0), qb = qa;
+        Quads qa = fetch(p0), qb = qa;
         if constexpr (LND > 0) {
             constexpr int NPC = LND / 32;
             f32x4 keep[2 * NPC];                  // the token's columns 16 t + 4 kq .. + 3, t = 0 .. D / 16 - 1
@@ -230,15 +233,15 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
                 *reinterpret_cast<uint2*>(frow + (long long)t * 512) = *reinterpret_cast<const uint2*>(o4);
             }
         } else {
-            for (int p = 0; p < NP; p += 2) {        // (NP = D / 32 is even: D is a multiple of 64)
+            for (int p = p0; p < p0 + NPY; p += 2) {        // (NPY is even: launch_embed)
                 qb = fetch(p + 1);
                 pair(p, qa);
-                qa = fetch(p + 2 < NP ? p + 2 : p + 1);
+                qa = fetch(p + 2 < p0 + NPY ? p + 2 : p + 1);
                 pair(p + 1, qb);
             }
         }
     }
-    if (((blockIdx.x * 8) & 15) == 0 && (int)(blockIdx.x * 8) / 16 < a.B) {   // the image's extra tokens: [label,] time (reference models/uvit.py:356-365)
+    if (blockIdx.y == 0 && ((blockIdx.x * 8) & 15) == 0 && (int)(blockIdx.x * 8) / 16 < a.B) {   // the image's extra tokens: [label,] time (reference models/uvit.py:356-365)
         const int bb = (blockIdx.x * 8) >> 4;
         const float t_raw = a.t_vec ? a.t_vec[bb] : a.st->t_model;
         const float tt = a.normalize ? t_raw / 1000.0f : t_raw;
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(512) embed_mfma_kernel(const EmbedArgs a) {
                 a.x_tok[((long long)bb * a.L + row) * D + d] = v + a.pos[(long long)row * D + d];
             }
     }
-    if (blockIdx.x == gridDim.x - 1) {   // padding rows of the workspace
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) {   // padding rows of the workspace
         const long long first = (long long)a.B * a.L * D, count = ((long long)a.Mp - (long long)a.B * a.L) * D;
         for (long long i = tid; i < count; i += 512) a.x_tok[first + i] = 0.f;
     }
@@ -901,12 +904,15 @@ bool embed_ln_supported(const EmbedArgs& a) {
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     size_t mlds = 0;
     if (!a.generic && embed_mfma_ok(a, mlds)) {
-        const dim3 grid((unsigned)((a.B * 16 + 7) / 8));
+        dim3 grid((unsigned)((a.B * 16 + 7) / 8));
         if (a.ln_frag) {      // + the first block's norm1 (embed_ln_supported)
             if (!embed_ln_supported(a) || !a.ln_g || !a.ln_b) return hipErrorInvalidValue;
             hipLaunchKernelGGL((embed_mfma_kernel<4, 3, 512>), grid, dim3(512), mlds, s, a);
             return hipGetLastError();
         }
+        // few images: deal the column pairs over grid.y until the launch has about one workgroup per CU (an even share of pairs each)
+        const int np = a.D / 32;
+        while (grid.x * grid.y * 2 <= 256 && np % (grid.y * 4) == 0) grid.y *= 2;
         if (a.P == 4) hipLaunchKernelGGL((embed_mfma_kernel<4, 3>), grid, dim3(512), mlds, s, a);
         else if (a.C == 3) hipLaunchKernelGGL((embed_mfma_kernel<2, 3>), grid, dim3(512), mlds, s, a);
         else hipLaunchKernelGGL((embed_mfma_kernel<2, 4>), grid, dim3(512), mlds, s, a);
@@ -963,38 +969,39 @@ template hipError_t launch_layernorm<float>(const float*, const float*, const fl
 // two-pass statistics as layernorm_kernel; Wg is parked in LDS in A-operand order once per workgroup.
 // HBM: the fp32 rows once (the launch's roof), dec once.
 // ------------------------------------------------------------------------------------------
-template <int D, int NT>
-__global__ void __launch_bounds__(512) head_dec_kernel(const HeadDecArgs a) {
+// NW waves per workgroup: 8 (two per SIMD: D <= 512, D / 4 row registers per lane), 4 at D = 768 / 1024 (192 / 256 row registers: one wave per SIMD).
+template <int D, int NT, int NW = 8>
+__global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) {
     constexpr int J = D / 16;
     extern __shared__ __attribute__((aligned(16))) char head_lds[];
     f32x4* wl = reinterpret_cast<f32x4*>(head_lds);                 // [J][NT][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     // Wg fragments of this wave (L2-resident) -> LDS in A-operand order, all loads in flight at once
-    constexpr int WI = J * NT / 8;
-    static_assert(J * NT % 8 == 0, "one equal share of Wg fragments per wave");
+    constexpr int WI = J * NT / NW;
+    static_assert(J * NT % NW == 0, "one equal share of Wg fragments per wave");
     {
         f32x4 wv[WI];
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const int item = wave + 8 * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
+            const int item = wave + NW * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
             wv[i] = *reinterpret_cast<const f32x4*>(a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q);
             if (m >= a.pd) wv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) wl[(wave + 8 * i) * 64 + lane] = wv[i];
+        for (int i = 0; i < WI; ++i) wl[(wave + NW * i) * 64 + lane] = wv[i];
     }
     f32x4 c4[NT];    // lane holds dec[row][16 ct + 4 q + i], i < 4 (pd % 4 == 0: a quad is inside or outside)
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) c4[ct] = *reinterpret_cast<const f32x4*>(a.c + (16 * ct + 4 * q < a.pd ? 16 * ct + 4 * q : 0));
     __syncthreads();
-    // 16-row units dealt to the waves of the whole grid, unit u -> wave (u / grid) % 8 of workgroup u % grid: with
+    // 16-row units dealt to the waves of the whole grid, unit u -> wave (u / grid) % NW of workgroup u % grid: with
     // M = B (256 + extras) rows the few units beyond one per wave land on different CUs (128-row tiles per workgroup
     // left one workgroup for a second round of the whole launch).  Nothing below synchronises across waves.
     // tok_l > 0: only the patch rows (tokens l >= tok_e of every tok_l-row image; 16 | tok_l - tok_e) are decoded -- the extra tokens'
     // rows of dec are never read (unpatchify takes the patch tokens, reference models/uvit.py:379-381) and at B = 128 those 128 rows
     // were 8 units more than one per wave: a second round of the whole launch on 8 CUs
     const int upi = a.tok_l > 0 ? (a.tok_l - a.tok_e) / 16 : 0;                       // units per image
-    const int units = a.tok_l > 0 ? (a.M / a.tok_l) * upi : (a.M + 15) / 16, stride = 8 * (int)gridDim.x;
+    const int units = a.tok_l > 0 ? (a.M / a.tok_l) * upi : (a.M + 15) / 16, stride = NW * (int)gridDim.x;
     for (int u = wave * (int)gridDim.x + (int)blockIdx.x; u < units; u += stride) {
         const long long row = a.tok_l > 0 ? (long long)(u / upi) * a.tok_l + a.tok_e + (u % upi) * 16 + n : (long long)u * 16 + n;
         const bool ok = row < a.M;
@@ -1046,7 +1053,11 @@ __global__ void __launch_bounds__(512) head_dec_kernel(const HeadDecArgs a) {
     }
 }
 
-bool head_dec_supported(int D, int pd) { return (D == 256 || D == 512) && pd >= 1 && pd <= 64 && pd % 4 == 0; }
+bool head_dec_supported(int D, int pd) {
+    if (pd < 1 || pd > 64 || pd % 4) return false;
+    const int nt = (pd + 15) / 16;
+    return D == 256 || D == 512 || (D == 768 && nt <= 3) || (D == 1024 && nt <= 2);     // (D / 16) nt KB of LDS for Wg
+}
 
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s) {
     if (!head_dec_supported(D, a.pd) || a.M < 1) return hipErrorInvalidValue;
@@ -1056,7 +1067,15 @@ hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t
     const dim3 grid((unsigned)(wgs < num_cus ? wgs : num_cus));     // one workgroup per CU (LDS), 16-row units dealt inside
     const size_t lds = (size_t)(D / 16) * nt * 1024;
 #define DD_HEAD(DV, NV) hipLaunchKernelGGL((head_dec_kernel<DV, NV>), grid, dim3(512), lds, s, a)
-    if (D == 512) { if (nt == 1) DD_HEAD(512, 1); else if (nt == 2) DD_HEAD(512, 2); else if (nt == 3) DD_HEAD(512, 3); else DD_HEAD(512, 4); }
+    if (D == 1024) {
+        if (nt == 1) hipLaunchKernelGGL((head_dec_kernel<1024, 1, 4>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((head_dec_kernel<1024, 2, 4>), grid, dim3(256), lds, s, a);
+    } else if (D == 768) {
+#define DD_HEAD4(NV) hipLaunchKernelGGL((head_dec_kernel<768, NV, 4>), grid, dim3(256), lds, s, a)
+        if (nt == 1) DD_HEAD4(1); else if (nt == 2) DD_HEAD4(2); else if (nt == 3) DD_HEAD4(3); else return hipErrorInvalidValue;
+#undef DD_HEAD4
+    }
+    else if (D == 512) { if (nt == 1) DD_HEAD(512, 1); else if (nt == 2) DD_HEAD(512, 2); else if (nt == 3) DD_HEAD(512, 3); else DD_HEAD(512, 4); }
     else { if (nt == 1) DD_HEAD(256, 1); else if (nt == 2) DD_HEAD(256, 2); else if (nt == 3) DD_HEAD(256, 3); else DD_HEAD(256, 4); }
 #undef DD_HEAD
     return hipGetLastError();
@@ -1070,6 +1089,12 @@ hipError_t init_rowops_kernels() {
     DD_HEAD_ATTR(512, 1) DD_HEAD_ATTR(512, 2) DD_HEAD_ATTR(512, 3) DD_HEAD_ATTR(512, 4)
     DD_HEAD_ATTR(256, 1) DD_HEAD_ATTR(256, 2) DD_HEAD_ATTR(256, 3) DD_HEAD_ATTR(256, 4)
 #undef DD_HEAD_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_dec_kernel<768, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_dec_kernel<768, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_dec_kernel<768, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_dec_kernel<1024, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_dec_kernel<1024, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<4, 3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
