@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <utility>
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -263,6 +264,55 @@ int run_kstep(const char* w, float* out, long long wbytes, int cus) {
     return 0;
 }
 
+template <bool AG> __device__ __forceinline__ void pin_acc(f32x16& y) { if constexpr (AG) asm volatile("" : "+a"(y)); else asm volatile("" : "+v"(y)); }
+template <bool AG, int OFF> __device__ __forceinline__ void gap_acc(f32x16& acc, bf16x8& fr, const bf16x8& fb, unsigned la) {
+    if constexpr (AG) asm volatile("s_waitcnt lgkmcnt(7)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\tds_read_b128 %1, %3 offset:%4" : "+a"(acc), "+v"(fr) : "v"(fb), "v"(la), "i"(OFF));
+    else asm volatile("s_waitcnt lgkmcnt(7)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\tds_read_b128 %1, %3 offset:%4" : "+v"(acc), "+v"(fr) : "v"(fb), "v"(la), "i"(OFF));
+}
+// rowlin's accumulator set: 24 independent 32 x 32 tiles per wave (384 registers), the first NA of them in AGPRs; no requests, barrier per k-step
+template <int NA>
+__global__ void __launch_bounds__(256) acc_probe(const char* __restrict__ w, float* out, int steps, long long wbytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[24];
+    for (int i = 0; i < 24; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 fr[8];
+    const bf16x8 fb = {1, 1, 1, 1, 1, 1, 1, 1};
+    const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem + lane * 16;
+    for (int i = 0; i < 8; ++i) fr[i] = fb;
+    [&]<int... T>(std::integer_sequence<int, T...>) { (pin_acc<(T < NA)>(acc[T]), ...); }(std::make_integer_sequence<int, 24>{});
+    for (int ks = 0; ks < steps; ++ks) {
+        [&]<int... M>(std::integer_sequence<int, M...>) {
+            (((M == 2 ? (void)__builtin_amdgcn_s_barrier() : (void)0), gap_acc<(M < NA), M * 1024>(acc[M], fr[M & 7], fb, la)), ...);
+        }(std::make_integer_sequence<int, 24>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    [&]<int... T>(std::integer_sequence<int, T...>) { (pin_acc<(T < NA)>(acc[T]), ...); }(std::make_integer_sequence<int, 24>{});
+    float s = 0.f;
+    for (int i = 0; i < 24; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+template <int NA>
+int run_acc(const char* w, float* out, long long wbytes, int cus) {
+    const int steps = 2048;
+    auto k = acc_probe<NA>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(cus), dim3(256), 144 * 1024, 0, w, out, 64, wbytes);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(cus), dim3(256), 144 * 1024, 0, w, out, steps, wbytes);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k-step, 24 independent accumulator tiles (%d in AGPRs), 24 x [MFMA + ds_read_b128], barrier per k-step: %8.3f ms = %5.0f cycles per k-step at 2.1 GHz (MFMA pipe alone: 768)\n", NA, ms,
+           ms * 1e-3 * 2.1e9 / steps);
+    fflush(stdout);
+    return 0;
+}
+
 template <int MF, int ROLE, int DMODE = 0>
 int run_role(const char* w, float* out, long long wbytes, int cus) {
     const int steps = 8192;
@@ -324,6 +374,7 @@ int main() {
     if (run_self<4, 0>(w, out, shared, cus) || run_self<4, 5>(w, out, shared, cus) || run_self<8, 0>(w, out, shared, cus) || run_self<8, 5>(w, out, shared, cus)) return 1;
     if (run_gap<4, 0, false>(w, out, shared, cus) || run_gap<4, 0, true>(w, out, shared, cus) || run_gap<4, 1, false>(w, out, shared, cus) || run_gap<4, 1, true>(w, out, shared, cus)) return 1;
     if (run_gap<4, 2, true>(w, out, shared, cus) || run_gap<8, 0, true>(w, out, shared, cus) || run_gap<8, 2, true>(w, out, shared, cus)) return 1;
+    if (run_acc<0>(w, out, shared, cus) || run_acc<16>(w, out, shared, cus) || run_acc<24>(w, out, shared, cus)) return 1;
     if (run_kstep<0, 1, false>(w, out, shared, cus) || run_kstep<0, 1, true>(w, out, shared, cus)) return 1;
     if (run_kstep<7, 3, false>(w, out, shared, cus) || run_kstep<7, 3, true>(w, out, shared, cus) || run_kstep<7, 2, true>(w, out, shared, cus) || run_kstep<7, 1, true>(w, out, shared, cus)) return 1;
     if (run_kstep<4, 3, true>(w, out, shared, cus)) return 1;
