@@ -776,10 +776,13 @@ int chain_gemm_cus(dd_ctx* c, dd_model* m, int B) {
     const int half = c->num_cus / 2 / 8 * 8;
     return half >= 8 ? half : c->num_cus;
 }
-int ensure_chain_ws(dd_ctx* c, dd_model* m) {
+// (zeroed ON THE LAUNCH STREAM: the second chain's stream is non-blocking, so a null-stream memset is not ordered before its first kernels --
+// the chain's first step ran while the memset was still sweeping the arena: the first images of the second half came out wrong on the very
+// first chained call of a model, intermittently)
+int ensure_chain_ws(dd_ctx* c, dd_model* m, hipStream_t s) {
     if (m->wsarena2) return DD_OK;
     DD_HIP(c, hipMalloc((void**)&m->wsarena2, m->wsoff.bytes));
-    DD_HIP(c, hipMemset(m->wsarena2, 0, m->wsoff.bytes));
+    DD_HIP(c, hipMemsetAsync(m->wsarena2, 0, m->wsoff.bytes, s));
     bind_ws(m->wsoff, m->wsarena2, m->ws2);
     return DD_OK;
 }
@@ -875,6 +878,7 @@ int dd_ctx_create(int device, dd_ctx** out) {
               hipEventCreateWithFlags(&c->ev_ee_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_ee_join, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipStreamSynchronize(nullptr) == hipSuccess;     // the null-stream memsets above, before any caller stream touches the state
     ok = ok && init_gemm_kernels() == hipSuccess && init_attention_kernels() == hipSuccess &&
          init_rowops_kernels() == hipSuccess && init_mlp_fused_kernels() == hipSuccess && init_rowlin_kernels() == hipSuccess;
     if (!ok) { dd_ctx_destroy(c); return DD_ERR_HIP; }
@@ -1213,6 +1217,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->wsoff = WsOffsets{o_x, o_h, o_ao, o_qkv, o_hid, o_xb, o_dec, o_part, o_dump, o_hf, off, o_sk, part_bytes != 0, m->fused_qkv, m->fused_qa};
     DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
     DD_HIP(c, hipMemset(m->wsarena, 0, off));
+    DD_HIP(c, hipStreamSynchronize(nullptr));    // (callers run the model on non-blocking streams, which a null-stream memset does not order itself before)
     {
         WsPtrs w;
         bind_ws(m->wsoff, m->wsarena, w);
@@ -1396,8 +1401,8 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
                 swap_chain(m); std::swap(c->st, c->st2);
                 return r;
             };
-            if ((rc = ensure_chain_ws(c, a->first)) || (rc = get_graph(c, a->first, 3, key1, s, step1))) return rc;
-            if (switching && ((rc = ensure_chain_ws(c, a->late)) || (rc = get_graph(c, a->late, 3, key1, s, step1)))) return rc;
+            if ((rc = ensure_chain_ws(c, a->first, s)) || (rc = get_graph(c, a->first, 3, key1, s, step1))) return rc;
+            if (switching && ((rc = ensure_chain_ws(c, a->late, s)) || (rc = get_graph(c, a->late, 3, key1, s, step1)))) return rc;
         }
     }
     DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
@@ -1489,8 +1494,8 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
                 swap_chain(m); std::swap(c->st, c->st2);
                 return r;
             };
-            if ((rc = ensure_chain_ws(c, a->first)) || (rc = get_graph(c, a->first, 4, key1, s, step1))) return rc;
-            if (switching && ((rc = ensure_chain_ws(c, a->late)) || (rc = get_graph(c, a->late, 4, key1, s, step1)))) return rc;
+            if ((rc = ensure_chain_ws(c, a->first, s)) || (rc = get_graph(c, a->first, 4, key1, s, step1))) return rc;
+            if (switching && ((rc = ensure_chain_ws(c, a->late, s)) || (rc = get_graph(c, a->late, 4, key1, s, step1)))) return rc;
         }
     }
     DD_HIP(c, launch_set_state_table(c->st, c->atab, (unsigned long long)a->seed, s));
@@ -1645,8 +1650,8 @@ int dd_profile_steps_chained(dd_ctx* c, dd_model* m, float* x_dev, const int64_t
     int rc = check_call(c, m, B, y_dev);
     if (rc) return rc;
     if (!x_dev || !ms_out || steps < 1 || t_start > 999 || t_start - steps + 1 < 0 || (B & 1) || B < 2) return fail(c, DD_ERR_INVALID, "bad arguments");
-    if ((rc = ensure_chain_ws(c, m))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = ensure_chain_ws(c, m, s))) return rc;
     const int B0 = B / 2, B1 = B - B0;
     const size_t chw = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
     DD_HIP(c, hipEventRecord(c->ev_fork, s));

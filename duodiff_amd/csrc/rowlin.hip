@@ -187,41 +187,65 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     // ---- epilogue: lane = row, register quad q of tile t = columns 32 t + 8 q + 4 h .. + 3
     // (a k-slice of the extra-token rows: the partial sums alone go to this workgroup's slab -- mlp_reduce_kernel adds bias, x and the slabs in
     // a fixed order; the same code path with the slab as the destination, so that the 384 accumulators are read in one place)
+    // The residual rows come in by LDS-DMA, 256 columns of the wave's 32 rows at a time (32 requests = 32 KB in flight per wave): the ring is free now,
+    // and register loads -- a handful in flight next to 384 accumulator registers -- left the epilogue latency-bound (190 of the fc2 launch's 455 us).
+    asm volatile("s_barrier" ::: "memory");          // every wave's fragment reads of the ring are done
+    constexpr int kPitch = 1024 + 16;                 // lane = row reads of a column quad: 16 consecutive rows fall into 16 different bank groups
+    char* strip = smem + wave * (32 * kPitch);
     bool ok;
     const long long rr = row_of(arow, ok);
+    bool ok0;
+    const long long row0w = __builtin_amdgcn_readfirstlane((int)row_of(32 * wave, ok0));      // the wave's 32 rows are consecutive token rows (tok_n % 32 == 0)
+    const int limit = !planned ? a.M : a.n_main;
+    const long long rows_all = planned ? (long long)(a.n_main / a.tok_n) * a.tok_l : a.M;
+    int nvalid = limit - (tile * 128 + 32 * wave);
+    nvalid = part_tile ? 32 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
     // (straight-line: residual and bias enter through a 0 / 1 factor -- exact either way -- a branch or select here makes hipcc spill 350 registers)
-    const float* xin = a.xres + rr * kRlD + 4 * h;
-    float* xr = part_tile ? a.partial + ((long long)xe * 128 + arow) * kRlD + 4 * h : a.xres + rr * kRlD + 4 * h;
     const float keep = part_tile ? 0.f : 1.f;
     ok = ok || part_tile;
-    bf16_t* cr = a.x_copy && !part_tile ? a.x_copy + rr * kRlD + 8 * h : nullptr;
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
     float cshift = 0.f;
 #pragma unroll
-    for (int t = 0; t < kRlNT; ++t) {
-        uint2 cv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + 32 * t + 8 * q);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * t + 8 * q + 4 * h);
-            f32x4 v = {Y[t][4 * q], Y[t][4 * q + 1], Y[t][4 * q + 2], Y[t][4 * q + 3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], keep, v[e] + bv[e] * keep);
-            if (ok) *reinterpret_cast<f32x4*>(xr + 32 * t + 8 * q) = v;
-            cv[q] = uint2{rl_pack2(v[0], v[1]), rl_pack2(v[2], v[3])};
-            if (t == 0 && q == 0) cshift = v[0];
-            const f32x4 d = v - cshift;
-            s4 += d;
-            q4 += d * d;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Y[t][4 * q + e] = v[e];
+    for (int p = 0; p < 3; ++p) {
+        {   // (a slab tile fetches 32 residual rows from its first token on, clamped to the last row -- finite values that its 0 factor drops)
+            const char* src = reinterpret_cast<const char*>(a.xres + 256 * p) + lane * 16;
+            for (int i = 0; i < nvalid; ++i) {
+                const long long ri = row0w + i < rows_all ? row0w + i : rows_all - 1;
+                __builtin_amdgcn_global_load_lds((rl_gptr_t)(src + ri * (kRlD * 4)), (rl_lptr_t)(strip + i * kPitch), 16, 0, 0);
+            }
         }
-        if (cr) {            // bf16 copy of the updated rows (a long-skip tensor / the next skip_linear's operand): 16-byte row segments
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int qp = 0; qp < 4; qp += 2) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(cv[qp].x, cv[qp + 1].x, false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(cv[qp].y, cv[qp + 1].y, false, false);
-                if (ok) *reinterpret_cast<uint4*>(cr + 32 * t + 8 * qp) = uint4{s0[0], s1[0], s0[1], s1[1]};
+        for (int tt = 0; tt < 8; ++tt) {
+            const int t = 8 * p + tt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4* sl = reinterpret_cast<f32x4*>(strip + r32 * kPitch + (32 * tt + 8 * q + 4 * h) * 4);
+                const f32x4 xv = *sl;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * t + 8 * q + 4 * h);
+                f32x4 v = {Y[t][4 * q], Y[t][4 * q + 1], Y[t][4 * q + 2], Y[t][4 * q + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], keep, v[e] + bv[e] * keep);
+                *sl = v;
+                if (t == 0 && q == 0) cshift = v[0];
+                const f32x4 d = v - cshift;
+                s4 += d;
+                q4 += d * d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Y[t][4 * q + e] = v[e];
+            }
+        }
+        // the updated rows leave as whole 1 KB segments (lane = 16-byte column chunk), the bf16 copy as 512-byte segments
+        {
+            float* dst = (part_tile ? a.partial + ((long long)xe * 128 + 32 * wave) * kRlD : a.xres + row0w * kRlD) + 256 * p + 4 * lane;
+            bf16_t* cp = a.x_copy && !part_tile ? a.x_copy + row0w * kRlD + 256 * p + 4 * lane : nullptr;
+#pragma unroll 4
+            for (int i = 0; i < 32; ++i) {
+                if (i < nvalid) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(strip + i * kPitch + lane * 16);
+                    *reinterpret_cast<f32x4*>(dst + (long long)i * kRlD) = v;
+                    if (cp) *reinterpret_cast<uint2*>(cp + (long long)i * kRlD) = uint2{rl_pack2(v[0], v[1]), rl_pack2(v[2], v[3])};
+                }
             }
         }
     }
@@ -242,8 +266,10 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
         const float shift = -mean * rstd;
         // row-major rows, or (h_frag: main tiles) the MFMA fragment order the attention launch loads: [32-row group][k-step][lane] x 16 bytes --
         // the 16-byte piece of (tile t, quad pair qp) is k-step 2 t + qp / 2 of this wave's group, at this lane's slot
-        bf16_t* hr = a.h_frag ? a.h_frag + (((long long)tile * 4 + wave) * (kRlD / 16) * 64 + lane) * 8 : a.h_out + rr * kRlD + 8 * h;
-        const long long hstride = a.h_frag ? 512 : 16;                 // elements between consecutive k-steps' pieces
+        // fragment order: whole 1 KB pieces per request as the registers stand.  Row-major (the next GEMM's operand): turned through the strip, 384
+        // columns at a time, so that a request stores 768 contiguous bytes of one row instead of 32 rows x 16 bytes
+        constexpr int kHPitch = 768 + 16;
+        bf16_t* hr = a.h_frag ? a.h_frag + (((long long)tile * 4 + wave) * (kRlD / 16) * 64 + lane) * 8 : nullptr;
 #pragma unroll
         for (int t = 0; t < kRlNT; ++t) {
             uint2 v[4];
@@ -258,7 +284,15 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
             for (int qp = 0; qp < 4; qp += 2) {      // 16-byte row segments (v_permlane32_swap pairs the lane halves)
                 const auto s0 = __builtin_amdgcn_permlane32_swap(v[qp].x, v[qp + 1].x, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(v[qp].y, v[qp + 1].y, false, false);
-                if (ok) *reinterpret_cast<uint4*>(hr + (2 * t + qp / 2) * hstride) = uint4{s0[0], s1[0], s0[1], s1[1]};
+                const uint4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (hr) { if (ok) *reinterpret_cast<uint4*>(hr + (2 * t + qp / 2) * 512) = o; }
+                else *reinterpret_cast<uint4*>(strip + r32 * kHPitch + (32 * (t % 12) + 8 * qp + 8 * h) * 2) = o;
+            }
+            if (!hr && t % 12 == 11) {
+                bf16_t* dst = a.h_out + row0w * kRlD + 384 * (t / 12) + 8 * lane;
+#pragma unroll 4
+                for (int i = 0; i < 32; ++i)
+                    if (i < nvalid && lane < 48) *reinterpret_cast<uint4*>(dst + (long long)i * kRlD) = *reinterpret_cast<const uint4*>(strip + i * kHPitch + lane * 16);
             }
         }
     }

@@ -298,6 +298,7 @@ int dd_vae_finalize(dd_vae* v, int precision) {
     const size_t o_ao = take(Bc * HWm * Cm * 4), o_z4 = take(Bc * HWm * 4 * 4);
     VHIP(c, hipMalloc((void**)&v->ws, off));
     VHIP(c, hipMemset(v->ws, 0, off));
+    VHIP(c, hipStreamSynchronize(nullptr));      // (ditto capi.hip: ordered before any stream the decoder is later run on)
     v->s0 = (float*)(v->ws + o_s0); v->s1 = (float*)(v->ws + o_s1); v->h1 = (float*)(v->ws + o_h1);
     v->nb = v->ws + o_nb; v->col = v->ws + o_col; v->part = (float*)(v->ws + o_part);
     v->q = v->ws + o_q; v->kk = v->ws + o_k; v->vt = v->ws + o_vt; v->pp = v->ws + o_pp;
