@@ -15,7 +15,7 @@ DD_EE_MLP_PER_LAYER, DD_EE_MLP_PER_TIMESTEP, DD_EE_MLP_PER_LAYER_PER_TIMESTEP, D
 ABI_VERSION = 4
 DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_EMBED, DD_DEV_MLP_EXTRAS_ONLY = 1, 2, 4, 8, 16
 DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV, DD_DEV_NO_FUSED_QA = 32, 64, 128
-DD_DEV_NO_CHAINS, DD_DEV_FORCE_CHAINS, DD_DEV_NO_ROWLIN, DD_DEV_NO_ROWLIN_PROJ, DD_DEV_NO_EMBED_LN, DD_DEV_NO_SPLITK = 256, 512, 1024, 2048, 4096, 8192
+DD_DEV_NO_CHAINS, DD_DEV_FORCE_CHAINS, DD_DEV_NO_ROWLIN, DD_DEV_NO_ROWLIN_PROJ, DD_DEV_NO_EMBED_LN, DD_DEV_NO_SPLITK, DD_DEV_NO_ROWLIN_SKIP = 256, 512, 1024, 2048, 4096, 8192, 16384
 
 
 class dd_config(C.Structure):

@@ -71,6 +71,7 @@ struct BlockW {
     const bf16_t* qa_img;    // attn.qkv weight per head in fragment order (qkv_attention_pack) or null
     const char* rl_img = nullptr;   // mlp.fc2 weight as the row-resident launch streams it (rowlin_pack) or null
     const char* rlp_img = nullptr;  // attn.proj weight, ditto
+    const char* rls_img = nullptr;  // skip_linear weight [D, 2 D], ditto (out-blocks)
 };
 
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred) or null
@@ -127,6 +128,7 @@ struct dd_model {
                                           //     whose heads read every block's output)
     bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
     bool splitk = false;                  // GEMM-path models whose N = embed_dim Linears have too few 256 x 256 tiles at max_batch: split-K + reduce_ln launches
+    bool rowlin_skip = false;             // ... and the out-blocks' skip_linear + norm1
     bool rowlin_proj = false;             // ... and attn.proj + residual + norm2 likewise
     bool rowlin_fc2 = false;              // embed_dim 768 on the GEMM path: mlp.fc2 + residual + the next block's norm1 in one row-resident launch (rowlin.hip)
     bool fused_qa = false;                // attn.qkv computed inside the attention launch (attention.hip qkv_attention_kernel): takes precedence over
@@ -498,7 +500,24 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
             bool done = false;
             if constexpr (sizeof(T) == 2) {
-                if (m->splitk) {     // split-K halves -> slabs; x = bias + slabs and this block's norm1 in the row pass behind it
+                if (m->rowlin_skip) {     // (embed_dim 768) x = skip_linear(cat[x, skip]) and this block's norm1 in one row-resident launch
+                    RowLinArgs ra{};
+                    ra.A = (const bf16_t*)xb; ra.A2 = (const bf16_t*)skip; ra.k_split = D; ra.set_x = 1; ra.lda = D; ra.K = 2 * D;
+                    ra.wimg = w.rls_img; ra.bias = w.skip_b; ra.xres = m->x; ra.partial = m->mlp_partial; ra.ln_g = w.ln1_g; ra.ln_b = w.ln1_b;
+                    if (m->fused_qa) ra.h_frag = m->hfrag; else ra.h_out = (bf16_t*)h;
+                    rowlin_plan(B, m->N, m->extras, L, 2 * D, ra);
+                    DD_HIP(c, launch_rowlin(ra, s));
+                    MlpFusedArgs fr{};
+                    fr.b2 = w.skip_b; fr.xres = m->x; fr.partial = m->mlp_partial; fr.ldo = D; fr.reduce_set = 1;
+                    fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
+                    fr.groups = ra.groups; fr.prows = 128;
+                    if (!m->fused_qa) { fr.ln_out_g = w.ln1_g; fr.ln_out_b = w.ln1_b; fr.ln_out = (bf16_t*)h; }
+                    DD_HIP(c, launch_mlp_reduce(fr, D, s));
+                    h_ready = true; qa_ready = m->fused_qa; done = true;
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                if (m->splitk && !done) {     // split-K halves -> slabs; x = bias + slabs and this block's norm1 in the row pass behind it
                     g.partial = m->mlp_partial; g.splits = 2;
                     DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
                     ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 0, w.skip_b, nullptr, D, w.ln1_g, w.ln1_b, (bf16_t*)h,
@@ -1011,6 +1030,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     // (embed_dim 768, no fused block tail) mlp.fc2 with the residual rows resident in registers: x read and written once, the next norm1 from registers
     m->rowlin_fc2 = precision == DD_PREC_BF16 && !m->fused_mlp && rowlin_supported(D, hid) && m->N % 32 == 0 && !(c->dev_flags & DD_DEV_NO_ROWLIN);
     m->rowlin_proj = m->rowlin_fc2 && !(c->dev_flags & DD_DEV_NO_ROWLIN_PROJ);
+    m->rowlin_skip = m->rowlin_fc2 && rowlin_supported(D, 2 * D) && !(c->dev_flags & DD_DEV_NO_ROWLIN_SKIP);
     // split-K for the N = embed_dim Linears (skip_linear, attn.proj, mlp.fc2) where even max_batch leaves half of the CUs without a 256 x 256
     // tile (ImageNet-256 latents: 32 x 4 tiles): a function of the model (max_batch), never of a call's batch
     m->splitk = precision == DD_PREC_BF16 && !m->fused_mlp && !m->rowlin_fc2 && D % 256 == 0 && !(c->dev_flags & DD_DEV_NO_SPLITK) &&
@@ -1019,7 +1039,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     for (int b = 1; m->splitk && b <= m->cfg.max_batch; ++b)     // every batch this model can be called with must fit the kernel's row partition
         m->splitk = gemm_splitk_supported(b * L, D, D, D, 2);
     auto put_raw = [&](size_t bytes) -> size_t { align(); const size_t off = host.size(); host.resize(off + bytes, 0); return off; };
-    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img, rl_img, rlp_img; bool skip; };
+    struct BlockOff { size_t ln1_g, ln1_b, ln2_g, ln2_b, proj_b, fc1_b, fc2_b, skip_b, qkv_w, proj_w, fc1_w, fc2_w, skip_w, mlp_img, mlp_b1p, qkv_b, qa_img, rl_img, rlp_img, rls_img; bool skip; };
     std::vector<BlockOff> boffs;
     // next_skip: prefix of the block whose skip_linear runs in THIS block's fused launch ("" = none)
     // next_qkv: prefix of the block whose attn.qkv runs in THIS block's fused launch ("" = none: the last block)
@@ -1060,6 +1080,10 @@ int dd_model_finalize(dd_model* m, int precision) {
             rowlin_pack(hid, P(p + "mlp.fc2.weight").data(), host_f2bf, (unsigned short*)&host[o.rl_img]);
             o.rlp_img = put_raw((size_t)D * D * 2);
             rowlin_pack(D, P(p + "attn.proj.weight").data(), host_f2bf, (unsigned short*)&host[o.rlp_img]);
+            if (skip) {
+                o.rls_img = put_raw((size_t)D * 2 * D * 2);
+                rowlin_pack(2 * D, P(p + "skip_linear.weight").data(), host_f2bf, (unsigned short*)&host[o.rls_img]);
+            }
         }
         boffs.push_back(o);
     };
@@ -1186,7 +1210,8 @@ int dd_model_finalize(dd_model* m, int precision) {
                  o.skip ? F(o.skip_b) : nullptr, m->cfg.qkv_bias ? F(o.qkv_b) : nullptr, V(o.qkv_w), V(o.proj_w), V(o.fc1_w), V(o.fc2_w),
                  o.skip ? V(o.skip_w) : nullptr, m->fused_mlp ? (const char*)V(o.mlp_img) : nullptr,
                  m->fused_mlp ? F(o.mlp_b1p) : nullptr, m->fused_qa ? (const bf16_t*)V(o.qa_img) : nullptr,
-                 m->rowlin_fc2 ? (const char*)V(o.rl_img) : nullptr, m->rowlin_fc2 ? (const char*)V(o.rlp_img) : nullptr};
+                 m->rowlin_fc2 ? (const char*)V(o.rl_img) : nullptr, m->rowlin_fc2 ? (const char*)V(o.rlp_img) : nullptr,
+                 m->rowlin_fc2 && o.skip ? (const char*)V(o.rls_img) : nullptr};
         m->blocks.push_back(w);
     }
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
@@ -1210,7 +1235,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_dec = take(Mp * m->pd * 4);
     const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid)
                               : m->splitk ? (size_t)2 * m->Mp_max * D * 4
-                              : m->rowlin_fc2 ? std::max(rowlin_partial_bytes(m->cfg.max_batch, m->extras, hid), rowlin_partial_bytes(m->cfg.max_batch, m->extras, D)) : 0;
+                              : m->rowlin_fc2 ? std::max(std::max(rowlin_partial_bytes(m->cfg.max_batch, m->extras, hid), rowlin_partial_bytes(m->cfg.max_batch, m->extras, 2 * D)), rowlin_partial_bytes(m->cfg.max_batch, m->extras, D)) : 0;
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
     const size_t o_hf = take(m->fused_qa ? (size_t)m->cfg.max_batch * m->N * D * 2 : 0);

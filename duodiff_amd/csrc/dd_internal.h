@@ -136,6 +136,7 @@ struct MlpFusedArgs {
     int n_main, n_extra;   // B * tok_n patch rows (main tiles), B * tok_e extra rows (hidden-split tiles)
     int tiles_main, tiles_left, groups, cpg;
     int prows;             // rows per hidden-split tile (32, 64 or 128: whole waves)
+    int reduce_set = 0;    // launch_mlp_reduce: x = b2 + slabs instead of x += (the extra-token rows of a row-resident skip_linear)
 };
 bool mlp_fused_supported(int D, int hidden);
 size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip, bool with_qkv);
@@ -158,6 +159,9 @@ hipError_t init_mlp_fused_kernels();
 // ---- row-resident Linear + bias + residual + LayerNorm for embed_dim 768 (rowlin.hip): x += A . W^T + b ; LayerNorm(x) g + beta as bf16
 struct RowLinArgs {
     const bf16_t* A;       // [rows, lda] bf16 rows of the Linear's input (k contiguous)
+    const bf16_t* A2;      // k_split > 0: the input is cat[A | A2] along k (skip_linear): k >= k_split comes from A2 [rows, lda]
+    int k_split;           // a multiple of 64, or 0
+    int set_x;             // != 0: x = A . W^T + b (no residual: skip_linear), else x += ...
     int lda, K;            // K % 64 == 0
     const char* wimg;      // rowlin_pack image of W [768, K]
     const float* bias;     // [768]

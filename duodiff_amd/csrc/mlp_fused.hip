@@ -1026,7 +1026,7 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
         }
     float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < VPL; ++e) { xv[e] += acc[e]; xp[e] = xv[e]; sum += xv[e]; }
+    for (int e = 0; e < VPL; ++e) { xv[e] = a.reduce_set ? acc[e] : xv[e] + acc[e]; xp[e] = xv[e]; sum += xv[e]; }
     if (a.out) {
 #pragma unroll
         for (int e = 0; e < VPL; ++e) a.out[row * a.ldo + col + e] = f2bf(xv[e]);

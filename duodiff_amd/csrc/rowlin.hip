@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     // fetches the 16-byte chunk that belongs in its slot (source-side XOR swizzle: slot s of row r holds chunk s ^ ((r >> 1) & 7))
     const int lr = lane >> 3;
     unsigned arows[4];          // this lane's four operand rows (one per piece) at the first k of the range: byte offsets (launch_rowlin checks 4 GB)
-    const char* abase_g = reinterpret_cast<const char*>(a.A);
+    // cat[A | A2] along k (skip_linear): groups of 64 k at or behind k_split read A2 (shifted so that the lane offsets, which carry the absolute k, still apply)
+    const char* abase_1 = reinterpret_cast<const char*>(a.A);
+    const char* abase_2 = a.k_split > 0 ? reinterpret_cast<const char*>(a.A2) - (long long)a.k_split * 2 : abase_1;
+    const int g_split = a.k_split > 0 ? (a.k_split >> 6) - (ks0 >> 2) : (1 << 30);       // first group (relative to this workgroup's range) that reads A2
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         bool okr;
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((rl_gptr_t)(abase_g + (arows[i] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((rl_gptr_t)((g < g_split ? abase_1 : abase_2) + (arows[i] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
         }
     };
     // ... and one piece at a time (the loop spreads a k-step's requests over its MFMA gaps: an LDS-DMA instruction costs 60-185 cycles of
@@ -122,7 +125,7 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     };
     auto dma_a1 = [&](int g, int j) {
         const int pc = wave * 4 + j;
-        __builtin_amdgcn_global_load_lds((rl_gptr_t)(abase_g + (arows[j] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rl_gptr_t)((g < g_split ? abase_1 : abase_2) + (arows[j] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
     };
     // prologue: A groups 0, 1; weights of k-steps 0, 1, 2
     dma_a(0);
@@ -201,13 +204,16 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     int nvalid = limit - (tile * 128 + 32 * wave);
     nvalid = part_tile ? 32 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
     // (straight-line: residual and bias enter through a 0 / 1 factor -- exact either way -- a branch or select here makes hipcc spill 350 registers)
-    const float keep = part_tile ? 0.f : 1.f;
+    const float keep = part_tile || a.set_x ? 0.f : 1.f, keepb = part_tile ? 0.f : 1.f;      // residual / bias factors
     ok = ok || part_tile;
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
     float cshift = 0.f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        {   // (a slab tile fetches 32 residual rows from its first token on, clamped to the last row -- finite values that its 0 factor drops)
+        if (a.set_x) {   // no residual: the strip (leftover ring bytes) is zeroed so that the 0 factor meets finite values
+#pragma unroll
+            for (int j = 0; j < 32; ++j) *reinterpret_cast<f32x4*>(strip + r32 * kPitch + (h * 32 + j) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {   // (a slab tile fetches 32 residual rows from its first token on, clamped to the last row -- finite values that its 0 factor drops)
             const char* src = reinterpret_cast<const char*>(a.xres + 256 * p) + lane * 16;
             for (int i = 0; i < nvalid; ++i) {
                 const long long ri = row0w + i < rows_all ? row0w + i : rows_all - 1;
@@ -225,7 +231,7 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * t + 8 * q + 4 * h);
                 f32x4 v = {Y[t][4 * q], Y[t][4 * q + 1], Y[t][4 * q + 2], Y[t][4 * q + 3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], keep, v[e] + bv[e] * keep);
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv[e], keep, v[e] + bv[e] * keepb);
                 *sl = v;
                 if (t == 0 && q == 0) cshift = v[0];
                 const f32x4 d = v - cshift;
@@ -335,6 +341,7 @@ size_t rowlin_partial_bytes(int max_batch, int extras, int K) {
 
 hipError_t launch_rowlin(const RowLinArgs& a, hipStream_t s) {
     if (!rowlin_supported(kRlD, a.K) || (a.tok_n <= 0 && a.M < 1) || !a.A || !a.wimg || !a.bias || !a.xres) return hipErrorInvalidValue;
+    if (a.k_split && (a.k_split % 64 || a.k_split >= a.K || !a.A2 || (a.tok_n > 0 && (a.cpg * 16) % 64))) return hipErrorInvalidValue;
     const long long rows_all = a.tok_n > 0 ? (long long)(a.n_main / a.tok_n) * a.tok_l : a.M;
     if (rows_all * a.lda * 2 >= (1ll << 32)) return hipErrorInvalidValue;     // the kernel's operand row offsets are 32 bits
     const int grid = a.tok_n > 0 ? a.tiles_main + a.tiles_extra * a.groups : (a.M + 127) / 128;

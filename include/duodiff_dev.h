@@ -55,6 +55,7 @@ int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const flo
 #define DD_DEV_NO_ROWLIN_PROJ 2048u  /* embed_dim 768: keep attn.proj as a GEMM + LayerNorm launch pair */
 #define DD_DEV_NO_EMBED_LN 4096u     /* keep the first block's norm1 as its own launch (default: written by the patch-embed launch where it fits) */
 #define DD_DEV_NO_SPLITK 8192u       /* small-batch GEMM-path models: keep skip_linear / attn.proj / mlp.fc2 as whole-K GEMMs + LayerNorm launches */
+#define DD_DEV_NO_ROWLIN_SKIP 16384u /* embed_dim 768: keep the out-blocks' skip_linear as a GEMM + LayerNorm launch pair */
 #define DD_DEV_FORCE_CHAINS 512u    /* dd_sample: two half-batch chains for ANY even batch (tests at small batches) */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
 

@@ -581,12 +581,12 @@ def test_kernel_variant_flags_agree_with_the_default_path(flags):
     assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
 
 
-@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 1024), (32, 3, 2048), (16, 5, 0), (16, 5, 1024)])
+@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 1024), (32, 3, 2048), (32, 3, 16384), (16, 5, 0), (16, 5, 1024)])
 def test_row_resident_fc2_at_embed_dim_768(img, B, flags):
     """embed_dim 768 (the ImageNet-64 width) has no fused block tail; its mlp.fc2 + residual + the next block's norm1 run as one
     row-resident launch (rowlin.hip), the extra-token rows K-split into slabs.  5-block class-conditional models: 256 patches
     (norm1 leaves in the attention launch's fragment order; flags 128: row-major, the qkv GEMM reads it) and 64 patches at B = 5
-    (a ragged 128-row tile), each against the oracle like the GEMM + LayerNorm pairs it replaces (flags 1024; 2048: attn.proj + norm2 alone stay a GEMM pair)."""
+    (a ragged 128-row tile), each against the oracle like the GEMM + LayerNorm pairs it replaces (flags 1024; 2048: attn.proj + norm2 alone stay a GEMM pair; 16384: the out-blocks' skip_linear + norm1 do)."""
     from duodiff_amd.engine import Context
     cfg = dict(img_size=img, patch_size=2, in_chans=3, embed_dim=768, depth=5, num_heads=12, mlp_ratio=4, qkv_bias=False,
                mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
