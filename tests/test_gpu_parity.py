@@ -581,38 +581,39 @@ def test_kernel_variant_flags_agree_with_the_default_path(flags):
     assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
 
 
-@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 1024), (32, 3, 2048), (32, 3, 16384), (16, 5, 0), (16, 5, 1024)])
-def test_row_resident_fc2_at_embed_dim_768(img, B, flags):
+@pytest.mark.parametrize("img,B,flags,ncls", [(32, 3, 0, 10), (32, 3, 128, 10), (32, 3, 1024, 10), (32, 3, 2048, 10), (32, 3, 16384, 10), (16, 5, 0, 10), (16, 5, 1024, 10),
+                                               (32, 4, 0, -1), (16, 5, 0, -1)])
+def test_row_resident_fc2_at_embed_dim_768(img, B, flags, ncls):
     """embed_dim 768 (the ImageNet-64 width) has no fused block tail; its mlp.fc2 + residual + the next block's norm1 run as one
     row-resident launch (rowlin.hip), the extra-token rows K-split into slabs.  5-block class-conditional models: 256 patches
     (norm1 leaves in the attention launch's fragment order; flags 128: row-major, the qkv GEMM reads it) and 64 patches at B = 5
-    (a ragged 128-row tile), each against the oracle like the GEMM + LayerNorm pairs it replaces (flags 1024; 2048: attn.proj + norm2 alone stay a GEMM pair; 16384: the out-blocks' skip_linear + norm1 do)."""
+    (a ragged 128-row tile), class-conditional (two extra tokens per image) and unconditional (one), each against the oracle like the GEMM + LayerNorm pairs it replaces (flags 1024; 2048: attn.proj + norm2 alone stay a GEMM pair; 16384: the out-blocks' skip_linear + norm1 do)."""
     from duodiff_amd.engine import Context
     cfg = dict(img_size=img, patch_size=2, in_chans=3, embed_dim=768, depth=5, num_heads=12, mlp_ratio=4, qkv_bias=False,
-               mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
+               mlp_time_embed=False, num_classes=ncls, normalize_timesteps=True)
     g = torch.Generator().manual_seed(77 + img)
     x = torch.randn(B, 3, img, img, generator=g)
-    y = torch.randint(0, 10, (B,), generator=g)
+    y = torch.randint(0, 10, (B,), generator=g) if ncls > 0 else None
     t = torch.full((B,), 420.0)
-    want = _oracle(cfg, 4244)(x.numpy(), t.numpy(), y.numpy())
+    want = _oracle(cfg, 4244)(x.numpy(), t.numpy(), y.numpy() if y is not None else None)
     sigma = float(want.std())
     ctx = Context.get()
     try:
         ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
         m, _ = _uvit(cfg, 4244, "bf16", max_batch=B)
         got = m(x, t, y).cpu().numpy()
-        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous()).cpu().numpy()
+        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous() if y is not None else None).cpu().numpy()
         del m
     finally:
         ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
     err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
-    print(f"D=768 img {img} B={B} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+    print(f"D=768 img {img} B={B} classes {ncls} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
     assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
     assert np.array_equal(alone, got[B - 1:])        # the same image computed alone: bit-identical (no batch-dependent split)
 
 
-@pytest.mark.parametrize("img,B,flags", [(32, 3, 0), (32, 3, 128), (32, 3, 8192), (16, 5, 0)])
-def test_split_k_linears_at_embed_dim_1024(img, B, flags):
+@pytest.mark.parametrize("img,B,flags,ncls", [(32, 3, 0, 10), (32, 3, 128, 10), (32, 3, 8192, 10), (16, 5, 0, 10), (32, 4, 0, -1)])
+def test_split_k_linears_at_embed_dim_1024(img, B, flags, ncls):
     """embed_dim 1024 at small batches (the ImageNet-256 latent models): skip_linear, attn.proj and mlp.fc2 run as split-K halves of the
     256 x 256 kernel + one row pass (slabs + bias + residual + the LayerNorm behind the Linear).  5-block class-conditional models
     against the oracle, like the whole-K GEMM + LayerNorm launches they replace (flags 8192); flags 128: norm1 row-major for the
@@ -620,24 +621,24 @@ def test_split_k_linears_at_embed_dim_1024(img, B, flags):
     computed alone is bit-identical."""
     from duodiff_amd.engine import Context
     cfg = dict(img_size=img, patch_size=2, in_chans=4, embed_dim=1024, depth=5, num_heads=16, mlp_ratio=4, qkv_bias=False,
-               mlp_time_embed=False, num_classes=10, normalize_timesteps=True)
+               mlp_time_embed=False, num_classes=ncls, normalize_timesteps=True)
     g = torch.Generator().manual_seed(78 + img)
     x = torch.randn(B, 4, img, img, generator=g)
-    y = torch.randint(0, 10, (B,), generator=g)
+    y = torch.randint(0, 10, (B,), generator=g) if ncls > 0 else None
     t = torch.full((B,), 130.0)
-    want = _oracle(cfg, 4245)(x.numpy(), t.numpy(), y.numpy())
+    want = _oracle(cfg, 4245)(x.numpy(), t.numpy(), y.numpy() if y is not None else None)
     sigma = float(want.std())
     ctx = Context.get()
     try:
         ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
         m, _ = _uvit(cfg, 4245, "bf16", max_batch=B)
         got = m(x, t, y).cpu().numpy()
-        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous()).cpu().numpy()
+        alone = m(x[B - 1:].contiguous(), t[:1], y[B - 1:].contiguous() if y is not None else None).cpu().numpy()
         del m
     finally:
         ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
     err, rms = float(np.abs(got - want).max()), float(np.sqrt(((got - want).astype(np.float64) ** 2).mean()))
-    print(f"D=1024 img {img} B={B} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
+    print(f"D=1024 img {img} B={B} classes {ncls} dev_flags {flags}: vs oracle max {err:.3e} rms {rms:.3e} (sigma {sigma:.3f})")
     assert np.isfinite(got).all() and err <= 6e-2 * sigma and rms <= 1.4e-2 * sigma
     assert np.array_equal(alone, got[B - 1:])
 
