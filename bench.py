@@ -38,7 +38,17 @@ from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PROFILE_DIR = REPO / "profiles" / "r04"     # committed rocprofv3 --pmc summaries (tools/collect_pmc.sh), keyed by build id
+def _latest_profile_dir():
+    """The newest profiles/rNN that holds the headline workload's rocprofv3 kernel table (tools/collect_profiles.sh writes one per round)."""
+    ds = sorted((d for d in (REPO / "profiles").glob("r[0-9][0-9]") if (d / "kernel_stats.csv").exists()), reverse=True)
+    return ds[0] if ds else REPO / "profiles" / "r05"
+
+
+PROFILE_DIR = _latest_profile_dir()   # committed rocprofv3 summaries: kernel tables (which kernel dominates) and --pmc counters keyed by build id
+
+# kernel families the library can bracket with event pairs (include/duodiff.h DD_PROF_*): name fragment in rocprofv3's table -> kind
+FAMILIES = (("mlp_fused_kernel", "block_tail"), ("qkv_attention_kernel", "qkv_attention"), ("rowlin768_kernel", "rowlin"),
+            ("gemm256_kernel<1>", "fc1"), ("gemm256_kernel<5>", "splitk"))
 
 # BASELINE.json configs[1], [3], [4]: (label, shallow yaml, full yaml, batch per GPU, CPU-baseline sample (images, steps))
 WORKLOADS = {
@@ -191,6 +201,83 @@ def committed_pmc(build_id, workload, kernel_substr):
     return out, None
 
 
+def kernel_shares(workload):
+    """[(kind, name fragment, share of the GPU kernel time)] of the timeable kernel families, largest first, from the committed
+    rocprofv3 --kernel-trace --stats table of this workload's bench run (instantiations of one kernel are summed); [] if absent."""
+    import csv
+    sfx = "" if workload == "celeba" else f"_{workload}"
+    try:
+        rows = list(csv.DictReader(open(PROFILE_DIR / f"kernel_stats{sfx}.csv")))
+    except Exception:
+        return []
+    total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    fam = {}
+    for frag, kind in FAMILIES:
+        t = sum(float(r["TotalDurationNs"]) for r in rows if frag in r["Name"])
+        if t > 0:
+            fam[kind] = (frag, t / total)
+    return sorted(((k, f, sh) for k, (f, sh) in fam.items()), key=lambda e: -e[2])
+
+
+def family_model(kind, mp, B, dev_flags=0):
+    """Algorithmic FLOPs and HBM bytes per launch of one kernel family of the FULL backbone at batch B, averaged over the launches of one
+    forward (a family's launches differ: the block tail with / without the next skip_linear; attn.proj, mlp.fc2 and skip_linear share
+    one row-resident or split-K kernel), the rocprofv3 name fragment for the PMC lookup, and a description."""
+    D, Hd, L, N, depth, heads = mp.embed_dim, 4 * mp.embed_dim, mp.seq_len, mp.num_patches, mp.depth, mp.num_heads
+    M, Mp, nskip = B * L, B * N, mp.depth // 2
+    if kind == "block_tail":
+        # fc1 + fc2 of every row (the extra-token rows run in the launch's hidden-split workgroups) + attn.proj of the patch rows
+        fl = 2.0 * M * D * Hd * 2 + 2.0 * Mp * D * D
+        # fp32 residual rows read once and written once, the bf16 attention output read once, bf16 copy for the long skip, bf16 norm1
+        # output for the next block, the bf16 weights once
+        by = M * D * (4 + 4 + 2 + 2 + 2) + (2 * D * Hd + D * D) * 2
+        name = ("mlp_fused_kernel<%d>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d "
+                "(the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (D, M, D, Hd))
+        # depth // 2 of the depth launches per step also run the NEXT block's skip_linear on the patch rows (cat[y, skip] . Wskip^T:
+        # 2 M 2D D flops; its long-skip rows replace the bf16 copy in the byte count, + Wskip): the timed launches are that mix
+        ns = nskip if (D % 128 == 0 and not (dev_flags & 32)) else 0
+        if ns:
+            fl += ns / depth * 2.0 * Mp * 2 * D * D
+            by += int(ns / depth * 2 * D * D * 2)
+            name += "; %d of %d launches per step + the next block's skip_linear (flops and bytes averaged over the mix)" % (ns, depth)
+        return fl, by, "mlp_fused_kernel", name, depth
+    if kind == "fc1":
+        return (2.0 * M * D * Hd, M * D * 2 + M * Hd * 2 + D * Hd * 2, "gemm256_kernel<1>",
+                "gemm256_kernel<EPI_BIAS_GELU>: fc1 + bias + exact-erf GELU, M=%d K=%d N=%d" % (M, D, Hd), depth)
+    if kind == "qkv_attention":
+        fl = 2.0 * M * D * 3 * D + 4.0 * B * heads * L * L * 64
+        by = M * D * 2 * 2 + 3 * D * D * 2
+        return fl, by, "qkv_attention_kernel", ("qkv_attention_kernel<%d>: attn.qkv Linear + softmax(q k^T / 8) v per (image, head), norm1 rows in, "
+                                                 "attention rows out (the qkv tensor is never written), B=%d L=%d heads=%d" % (D, B, L, heads)), depth
+    if kind in ("rowlin", "splitk"):
+        # attn.proj (K = D) and mlp.fc2 (K = 4 D) of every block + skip_linear (K = 2 D) of the out-blocks: one kernel, three shapes
+        n = 2 * depth + nskip
+        fl = (depth * 2.0 * M * D * D + depth * 2.0 * M * D * Hd + nskip * 2.0 * M * 2 * D * D) / n
+        if kind == "rowlin":   # operand rows in (bf16), fp32 residual rows in + out (skip_linear: out only), LayerNorm rows out (bf16), mlp.fc2: bf16 copy, weights
+            by = (depth * (M * D * 2 + M * D * 8 + M * D * 2 + D * D * 2) + depth * (M * Hd * 2 + M * D * 8 + M * D * 4 + D * Hd * 2)
+                  + nskip * (M * 2 * D * 2 + M * D * 4 + M * D * 2 + 2 * D * D * 2)) / n
+            return fl, int(by), "rowlin768_kernel", ("rowlin768_kernel: x += A . W^T + b with the rows resident in registers + the LayerNorm behind it -- attn.proj, "
+                                                     "mlp.fc2 and skip_linear launches of a forward (%d + %d + %d), flops and bytes averaged over the mix, M=%d" % (depth, depth, nskip, M)), n
+        by = (depth * (M * D * 2 + D * D * 2) + depth * (M * Hd * 2 + D * Hd * 2) + nskip * (M * 2 * D * 2 + 2 * D * D * 2)) / n + 2 * M * D * 4   # operand + weights in, two fp32 slabs out
+        return fl, int(by), "gemm256_kernel<5>", ("gemm256_kernel<EPI_PARTIAL>: split-K halves of attn.proj / mlp.fc2 / skip_linear into fp32 slabs (%d + %d + %d launches of a "
+                                                  "forward; the row pass reduce_ln_kernel behind each is outside the event pair), M=%d" % (depth, depth, nskip, M)), n
+    raise ValueError(kind)
+
+
+def cu_share_half_batch(kind, mp, B):
+    """Share of the 256 CUs a HALF-batch launch of this family holds in the chained loop (one workgroup per CU for all of them)."""
+    Bh = B // 2
+    if kind == "block_tail" or kind == "rowlin":
+        return min(1.0, ((Bh * mp.num_patches + 127) // 128) / 256.0)
+    if kind == "qkv_attention":
+        return min(1.0, Bh * mp.num_heads / 256.0)
+    # persistent GEMM grids: both chains' grids are sized for half the CUs when the batch is large (capi.hip chain_gemm_cus)
+    if B * mp.seq_len > 32768:
+        return 0.5
+    col_tiles = 4 * mp.embed_dim // 256 if kind == "fc1" else 2 * (mp.embed_dim // 256)     # fc1: N = 4 D; split-K: N = D, two k halves per tile
+    return min(1.0, max(1, Bh * mp.seq_len // 256) * col_tiles / 256.0)
+
+
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
@@ -320,10 +407,11 @@ def main():
     gather_ms = ev_g0.elapsed_time(ev_g1) if (dist is not None and dist.get_backend() == "nccl") else 0.0
     # MAX over ranks of (wall, GPU ms of the K steps, all_gather ms, -GPU ms): the last entry gives the MIN, so that a slow or
     # late rank shows in the one line rank 0 prints
-    t_all = torch.tensor([dt, timing[0], gather_ms, -timing[0]], device=dev if on_dev else "cpu", dtype=torch.float64)
+    t_all = torch.tensor([dt, timing[0], gather_ms, -timing[0], -float(chains)], device=dev if on_dev else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt, gpu_ms_max, gather_ms_max, gpu_ms_min = float(t_all[0].item()), float(t_all[1].item()), float(t_all[2].item()), -float(t_all[3].item())
+    chains_min = int(round(-float(t_all[4].item())))     # a rank that fell back to one chain (odd batch, flag) shows here
     log(f"timed region done: {dt:.3f} s")
     finite = bool(torch.isfinite(imgs).all().item())
 
@@ -337,37 +425,26 @@ def main():
         #   D <= 512: the fused block tail (mlp_fused_kernel: attn.proj + residual + norm2 + fc1 + bias + exact-erf GELU + fc2 +
         #             bias + residual + next norm1 of the PATCH rows; the extra-token rows run in small launches outside the pair)
         #   else:     the fc1 GEMM (bias + GELU epilogue) of the two-GEMM path
-        with torch.cuda.stream(stream):
-            ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, y=y, stream=stream)
-            # ... and the same launches as the timed loop runs them when it splits the batch: two half-batch chains side by side
-            ms_ch, n_ch = ef.profile_steps_chained(x, t_start=699, steps=20, y=y, stream=stream) if chains == 2 else (None, 0)
-        D_, H_ = mp_f.embed_dim, 4 * mp_f.embed_dim
+        #   Which kernel: the one with the largest total time in the committed rocprofv3 kernel table of this workload's bench run
+        #   (profiles/rNN/kernel_stats*.csv); without a table, the design default (the fused block tail for embed_dim <= 512, else fc1).
+        D_ = mp_f.embed_dim
         fused = a.precision == "bf16" and D_ in (64, 128, 256, 512)
-        if fused:
-            M_rows = B * mp_f.seq_len                                  # fc1 + fc2 of every row (the extra-token rows run in the launch's
-            fl = 2.0 * M_rows * D_ * H_ * 2 + 2.0 * B * mp_f.num_patches * D_ * D_   # hidden-split workgroups) + attn.proj of the patch rows
-            # algorithmic bytes of one launch: fp32 residual rows read once and written once, the bf16 attention output read
-            # once, bf16 copy for the long skip, bf16 norm1 output for the next block, the bf16 weights once
-            alg_bytes = M_rows * D_ * (4 + 4 + 2 + 2 + 2) + (2 * D_ * H_ + D_ * D_) * 2
-            pmc_kernel = "mlp_fused_kernel"
-            kname = ("mlp_fused_kernel<%d>: attn.proj + residual + norm2 + fc1 + GELU + fc2 + residual + next norm1, M=%d D=%d hidden=%d "
-                     "(the small proj_rows / mlp_reduce launches of the extra-token rows are outside the event pair)" % (D_, M_rows, D_, H_))
-            # depth // 2 of the depth launches per step also run the NEXT block's skip_linear on the patch rows (cat[y, skip] . Wskip^T:
-            # 2 M 2D D flops; its long-skip rows replace the bf16 copy in the byte count, + Wskip): the timed launches are that mix
-            n_skip = mp_f.depth // 2 if (D_ % 128 == 0 and not (a.dev_flags & 32)) else 0
-            if n_skip:
-                fl += n_skip / mp_f.depth * 2.0 * B * mp_f.num_patches * 2 * D_ * D_
-                alg_bytes += int(n_skip / mp_f.depth * 2 * D_ * D_ * 2)
-                kname += "; %d of %d launches per step + the next block's skip_linear (flops and bytes averaged over the mix)" % (n_skip, mp_f.depth)
-        else:
-            M_rows = B * mp_f.seq_len
-            fl = 2.0 * M_rows * D_ * H_
-            alg_bytes = M_rows * D_ * 2 + M_rows * H_ * 2 + D_ * H_ * 2
-            pmc_kernel = "gemm256_kernel<1>"
-            kname = "gemm256_kernel<EPI_BIAS_GELU>: fc1 + bias + exact-erf GELU, M=%d K=%d N=%d" % (M_rows, D_, H_)
+        shares = kernel_shares(a.workload) if a.precision == "bf16" else []
+        kind = shares[0][0] if shares else ("block_tail" if fused else "fc1")
+        with torch.cuda.stream(stream):
+            ms, n_launch = ef.profile_steps(x, t_start=699, steps=20, y=y, stream=stream, kind=kind)
+            # ... and the same launches as the timed loop runs them when it splits the batch: two half-batch chains side by side
+            ms_ch, n_ch = ef.profile_steps_chained(x, t_start=699, steps=20, y=y, stream=stream, kind=kind) if chains == 2 else (None, 0)
+            # the next two kernels of the table, timed the same way (5 steps each): name, share of the GPU kernel time, fraction of the roof
+            top = []
+            for k2, frag, sh in shares[:3]:
+                m2, n2 = (ms, n_launch) if k2 == kind else ef.profile_steps(x, t_start=699, steps=5, y=y, stream=stream, kind=k2)
+                f2 = family_model(k2, mp_f, B, a.dev_flags)[0]
+                top.append({"name": frag, "share_of_kernel_time": sh, "ms_per_launch": m2, "launches_timed": n2, "flops_per_launch": f2,
+                            "frac": (f2 / (m2 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS) if m2 else None})
+        fl, alg_bytes, pmc_kernel, kname, _ = family_model(kind, mp_f, B, a.dev_flags)
         ach = fl / (ms * 1e-3) / 1e12
-        # main row tiles of a half-batch launch: 128-row tiles of the patch rows (fused tail) / 256-row tiles x column tiles (fc1 GEMM)
-        main_tiles_half = ((B // 2) * mp_f.num_patches + 127) // 128 if fused else ((B // 2) * mp_f.seq_len // 256) * (H_ // 256)
+        cu_share = cu_share_half_batch(kind, mp_f, B)     # CUs a half-batch launch of this kernel holds in the chained loop
         # HBM bytes / MFMA-busy fraction of that kernel: quoted from the COMMITTED rocprofv3 --pmc profile only when that profile
         # was collected on the build that is running (rocprofv3 cannot run inside this process); null + reason otherwise
         pm, why_not = committed_pmc(build_id, a.workload, pmc_kernel)
@@ -384,7 +461,7 @@ def main():
                        # dd_sample runs an even batch >= 32 as two independent half-batch chains on two streams (bit-identical results:
                        # one chain's HBM-bound phases overlap the other's MFMA phases); the roofline leg below times the kernel ALONE
                        # on the chip at the full batch, one chain
-                       "chains_in_timed_region": chains,
+                       "chains_in_timed_region": chains, "chains_min_over_ranks": chains_min,
                        "timed_steps": K, "switch_after_steps": k_switch,
                        "seconds_per_sample": (dt * 1000.0 / K) / images, "finite": finite,
                        "gpu_ms_total": timing[0], "gpu_ms_first_backbone": timing[1], "gpu_ms_late_backbone": timing[2],
@@ -399,6 +476,9 @@ def main():
                                             f"collected on this build ({build_id}); not measured in this run") if traffic else why_not,
                          "algorithmic_bytes": alg_bytes,
                          "kernel": kname,
+                         "kernel_chosen_from": (f"largest total time in {PROFILE_DIR.relative_to(REPO)}/kernel_stats{'' if a.workload == 'celeba' else '_' + a.workload}.csv"
+                                                if shares else "design default (no committed kernel table for this workload / precision)"),
+                         "kernels": top,
                          "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
                          "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
@@ -413,8 +493,8 @@ def main():
                          # its own roof is peak x T / 256; `frac` above is the conservative figure (the kernel alone, every CU in the same phase)
                          "chained": None if ms_ch is None else {
                              "ms_per_launch": ms_ch, "launches_timed": n_ch, "flops_per_launch": fl / 2, "achieved": fl / 2 / (ms_ch * 1e-3) / 1e12,
-                             "main_tiles_per_launch": main_tiles_half, "cu_share": min(1.0, main_tiles_half / 256.0),
-                             "frac_of_the_cus_it_holds": fl / 2 / (ms_ch * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS * min(1.0, main_tiles_half / 256.0)),
+                             "cu_share": cu_share,
+                             "frac_of_the_cus_it_holds": fl / 2 / (ms_ch * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS * cu_share),
                              "ms_per_launch_source": "measured live (hipEvents on both chains' streams, eager steps)"},
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "

@@ -41,6 +41,7 @@ struct dd_ctx {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float timing[3] = {0, 0, 0};
     int num_cus = 256;           // CU count the persistent GEMM grids are sized for (dd_set_num_cus), a multiple of 8
+    int base_cus = 256;          // ... as set; num_cus itself is halved while a chained call captures the graphs of a large GEMM-path batch
     // dd_sample's graphs run on context-owned staging copies of x / y, so a captured step does not depend on the caller's
     // tensor addresses (reference get_samples allocates a fresh x per call: the graphs would be re-captured every time)
     float* x_stage = nullptr;
@@ -52,6 +53,7 @@ struct dd_ctx {
     AffineRow* atab = nullptr;
     size_t atab_rows = 0;
     std::vector<AffineRow> atab_host;
+    int prof_kind = 0;           // dd_profile_select: which launches dd_profile_steps brackets (DD_PROF_*)
     unsigned dev_flags = 0;      // dd_dev_set_flags (include/duodiff_dev.h): kernel-variant switches of the development harness
 };
 
@@ -97,7 +99,7 @@ struct WsPtrs {
     std::vector<void*> skips;
     float* dec = nullptr; float* mlp_partial = nullptr; bf16_t* qkv_dump = nullptr; bf16_t* hfrag = nullptr;
 };
-struct WsOffsets { size_t x, h, ao, qkv, hid, xb, dec, part, dump, hf, bytes; std::vector<size_t> sk; bool has_part, has_dump, has_hf; };
+struct WsOffsets { size_t x, h, ao, qkv, hid, xb, dec, part, dump, hf, bytes; std::vector<size_t> sk; bool has_part, has_dump, has_hf; size_t part_bytes = 0; };
 
 struct dd_model {
     dd_ctx* ctx = nullptr;
@@ -139,12 +141,12 @@ struct dd_model {
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
     GraphKey gkey[5]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] / [4]: [0] / [1] of the second chain
-    WsOffsets wsoff{};
+    WsOffsets wsoff{}, wsoff2{};                             // layout of the main workspace (max_batch) and of the second chain's (half of it)
     char* wsarena2 = nullptr;                                // the second chain's workspace (allocated by the first chained dd_sample)
     WsPtrs ws2;
     float* ee_ws = nullptr;                                  // dd_sample_early_exit scratch: eps | model_output | cls | outs
     size_t ee_ws_elems = 0;
-    // in-context timing of the dominant kernel (fc1 GEMM): event pairs recorded around each launch when enabled
+    // in-context timing (dd_profile_steps): event pairs recorded around each launch of kind ctx->prof_kind when enabled
     bool time_fc1 = false;
     std::vector<hipEvent_t> fc1_events;   // pairs, grown on demand
     size_t fc1_used = 0;
@@ -411,6 +413,32 @@ void bind_ws(const WsOffsets& o, char* arena, WsPtrs& w) {
     w.qkv_dump = o.has_dump ? (bf16_t*)(arena + o.dump) : nullptr;
     w.hfrag = o.has_hf ? (bf16_t*)(arena + o.hf) : nullptr;
 }
+// Layout of one chain's activation workspace for batches up to `batch` (the model's max_batch; half of it, rounded up, for the second
+// half-batch chain of dd_sample, which never runs more).
+WsOffsets ws_layout(const dd_model* m, int batch) {
+    const int D = m->D, L = m->L, hid = m->hidden;
+    const size_t es = m->esize;
+    const size_t Mp = (size_t)round_up(batch * L, 256);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    // qkv is head-major: B * 3H units of Lp rows x 64 (rows [L, Lp) of a unit are never written: the bf16 attention launch that stages K / V
+    // from this tensor zeroes them in its LDS images itself)
+    const size_t qkv_elems = (size_t)batch * 3 * D * (size_t)make_head_major(L, m->H).Lp;
+    const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(std::max(Mp * 3 * D, qkv_elems) * es);
+    const size_t o_hid = take(Mp * (size_t)m->hid_ld * es), o_xb = take(Mp * D * es);
+    std::vector<size_t> o_sk;
+    for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
+    const size_t o_dec = take(Mp * m->pd * 4);
+    const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(batch, m->extras, D, hid)
+                              : m->splitk ? (size_t)2 * Mp * D * 4
+                              : m->rowlin_fc2 ? std::max(std::max(rowlin_partial_bytes(batch, m->extras, hid), rowlin_partial_bytes(batch, m->extras, 2 * D)), rowlin_partial_bytes(batch, m->extras, D)) : 0;
+    const size_t o_part = take(part_bytes);
+    const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
+    const size_t o_hf = take(m->fused_qa ? (size_t)batch * m->N * D * 2 : 0);
+    WsOffsets o{o_x, o_h, o_ao, o_qkv, o_hid, o_xb, o_dec, o_part, o_dump, o_hf, off, o_sk, part_bytes != 0, m->fused_qkv, m->fused_qa};
+    o.part_bytes = part_bytes;
+    return o;
+}
 // exchange the model's workspace pointers with the second chain's (the caller swaps the context's step state too): the launch sequence of a step is
 // enqueued / captured for that chain by the same code, on the same weights
 void swap_chain(dd_model* m) {
@@ -448,6 +476,21 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         DD_HIP(c, launch_time_mlp(ta, s));
     }
 
+    // in-context timing (dd_profile_steps): an event on s in front of and behind every launch of the selected kind
+    const int prof = c->prof_kind == DD_PROF_DOMINANT ? ((sizeof(T) == 2 && m->fused_mlp) ? DD_PROF_BLOCK_TAIL : DD_PROF_FC1) : c->prof_kind;
+    auto mark = [&](int kind) -> int {
+        if (!m->time_fc1 || kind != prof) return DD_OK;
+        while (m->fc1_events.size() < m->fc1_used + 1) {
+            hipEvent_t e;
+            DD_HIP(c, hipEventCreate(&e));
+            m->fc1_events.push_back(e);
+        }
+        DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used++], s));
+        return DD_OK;
+    };
+    // 128 x 128 or 256 x 256 tiles for a bf16 Linear: decided for the model's max_batch on the context's CU count -- never for the batch (or the
+    // chain-halved grid) of this call, so that a row takes the same kernel alone, in a full batch and in a half-batch chain
+    auto tile128 = [&](int N, int K, int K1) { return sizeof(T) == 2 && gemm_prefers_128(m->cfg.max_batch * L, N, K, K1, c->base_cus) ? 1 : 0; };
     T* h = (T*)m->h; T* ao = (T*)m->ao; T* qkv = (T*)m->qkv; T* hid = (T*)m->hid; T* xb = (T*)m->xb;
     const int nb = (int)m->blocks.size();
     bool h_ready = ln1_done;   // h already holds norm1 of the coming block (written by the fused MLP of the previous one / the embed launch)
@@ -498,6 +541,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             const int oi = bi - m->half_depth - 1;
             const T* skip = (const T*)m->skips[m->half_depth - 1 - oi];  // LIFO (uvit.py:374-375)
             GemmArgs<T> g{xb, skip, (const T*)w.skip_w, w.skip_b, m->x, nullptr, M, D, 2 * D, D, D, D, D};
+            g.tile128 = tile128(D, 2 * D, D);
             bool done = false;
             if constexpr (sizeof(T) == 2) {
                 if (m->rowlin_skip) {     // (embed_dim 768) x = skip_linear(cat[x, skip]) and this block's norm1 in one row-resident launch
@@ -506,7 +550,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     ra.wimg = w.rls_img; ra.bias = w.skip_b; ra.xres = m->x; ra.partial = m->mlp_partial; ra.ln_g = w.ln1_g; ra.ln_b = w.ln1_b;
                     if (m->fused_qa) ra.h_frag = m->hfrag; else ra.h_out = (bf16_t*)h;
                     rowlin_plan(B, m->N, m->extras, L, 2 * D, ra);
+                    if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                     DD_HIP(c, launch_rowlin(ra, s));
+                    if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                     MlpFusedArgs fr{};
                     fr.b2 = w.skip_b; fr.xres = m->x; fr.partial = m->mlp_partial; fr.ldo = D; fr.reduce_set = 1;
                     fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
@@ -519,7 +565,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             if constexpr (sizeof(T) == 2) {
                 if (m->splitk && !done) {     // split-K halves -> slabs; x = bias + slabs and this block's norm1 in the row pass behind it
                     g.partial = m->mlp_partial; g.splits = 2;
+                    if (int rc = mark(DD_PROF_SPLITK)) return rc;
                     DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                    if (int rc = mark(DD_PROF_SPLITK)) return rc;
                     ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 0, w.skip_b, nullptr, D, w.ln1_g, w.ln1_b, (bf16_t*)h,
                                     m->fused_qa ? m->hfrag : nullptr, L, m->extras, M};
                     DD_HIP(c, launch_reduce_ln(ra, D, s));
@@ -541,15 +589,19 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         }
         h_ready = false;
         if (qa_ready) {
+            if (int rc = mark(DD_PROF_QKV_ATTENTION)) return rc;
             if constexpr (sizeof(T) == 2)
                 DD_HIP(c, launch_qkv_attention(m->hfrag, w.qa_img, w.qkv_b, nullptr, m->x, w.ln1_g, w.ln1_b, (bf16_t*)ao, B, L, m->H, D, m->extras, s));
+            if (int rc = mark(DD_PROF_QKV_ATTENTION)) return rc;
         } else {
             if (!qkv_done) {
                 GemmArgs<T> g{h, nullptr, (const T*)w.qkv_w, w.qkv_b, nullptr, qkv, M, 3 * D, D, D, D, 0, 3 * D};
                 g.hm = make_head_major(L, m->H);     // head-major: each (q | k | v, head) unit of an image is contiguous (attention.hip)
                 DD_HIP(c, launch_gemm<T>(g, w.qkv_b ? EPI_BIAS_STORE : EPI_STORE, s, c->num_cus));
             }
+            if (int rc = mark(DD_PROF_QKV_ATTENTION)) return rc;
             DD_HIP(c, launch_attention<T>(qkv, ao, B, L, m->H, D, s));
+            if (int rc = mark(DD_PROF_QKV_ATTENTION)) return rc;
         }
         qkv_done = false; qa_ready = false;
         if (ee_side) {     // the head / probe launches have read x: from here on the block updates it
@@ -564,7 +616,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 ra.A = (const bf16_t*)ao; ra.lda = D; ra.K = D; ra.wimg = w.rlp_img; ra.bias = w.proj_b; ra.xres = m->x;
                 ra.partial = m->mlp_partial; ra.ln_g = w.ln2_g; ra.ln_b = w.ln2_b; ra.h_out = (bf16_t*)h;
                 rowlin_plan(B, m->N, m->extras, L, D, ra);
+                if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                 DD_HIP(c, launch_rowlin(ra, s));
+                if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                 MlpFusedArgs fr{};
                 fr.b2 = w.proj_b; fr.xres = m->x; fr.partial = m->mlp_partial; fr.ldo = D;
                 fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
@@ -578,7 +632,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             if (m->splitk && !ln2_done) {     // attn.proj as split-K halves; x += bias + slabs and norm2 in the row pass behind it
                 GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, nullptr, nullptr, nullptr, M, D, D, D, D, 0, D};
                 g.partial = m->mlp_partial; g.splits = 2;
+                if (int rc = mark(DD_PROF_SPLITK)) return rc;
                 DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                if (int rc = mark(DD_PROF_SPLITK)) return rc;
                 ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 1, w.proj_b, nullptr, D, w.ln2_g, w.ln2_b, (bf16_t*)h, nullptr, L, m->extras, M};
                 DD_HIP(c, launch_reduce_ln(ra, D, s));
                 ln2_done = true;
@@ -586,22 +642,13 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         }
         if (!ln2_done && !(sizeof(T) == 2 && m->fused_proj)) {   // fused: x += proj(ao) + b happens inside the fused MLP launch below
             GemmArgs<T> g{ao, nullptr, (const T*)w.proj_w, w.proj_b, m->x, nullptr, M, D, D, D, D, 0, D};
+            g.tile128 = tile128(D, D, D);
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
         if (!ln2_done && !(sizeof(T) == 2 && m->fused_mlp)) DD_HIP(c, launch_layernorm<T>(m->x, w.ln2_g, w.ln2_b, h, M, D, s));   // fused MLP: norm2 in its prologue
         // the T-typed copy of the block output feeds a later skip_linear: as the `skip`
         // operand (in-blocks) or as the `x` operand (mid / out blocks, except the last)
         T* copy = is_in ? (T*)m->skips[bi] : (bi + 1 < nb ? xb : nullptr);
-        auto mark = [&]() -> int {   // in-context timing of the dominant kernel (dd_profile_steps)
-            if (!m->time_fc1) return DD_OK;
-            while (m->fc1_events.size() < m->fc1_used + 1) {
-                hipEvent_t e;
-                DD_HIP(c, hipEventCreate(&e));
-                m->fc1_events.push_back(e);
-            }
-            DD_HIP(c, hipEventRecord(m->fc1_events[m->fc1_used++], s));
-            return DD_OK;
-        };
         if constexpr (sizeof(T) == 2) {
             if (m->fused_mlp) {
                 MlpFusedArgs fa{};
@@ -637,9 +684,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
                 if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
-                if (int rc = mark()) return rc;
+                if (int rc = mark(DD_PROF_BLOCK_TAIL)) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
-                if (int rc = mark()) return rc;              // (the event pair brackets the fused kernel alone)
+                if (int rc = mark(DD_PROF_BLOCK_TAIL)) return rc;              // (the event pair brackets the fused kernel alone)
                 if (skip_next) {
                     MlpFusedArgs fr = fa;                    // the reduce kernel finishes y of the extra-token rows (fp32 + the bf16
                     fr.ln_out = nullptr;                     // copy in xb); their skip_linear + norm1 follow in one small launch
@@ -660,10 +707,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         }
         {
             GemmArgs<T> g{h, nullptr, (const T*)w.fc1_w, w.fc1_b, nullptr, hid, M, m->hidden, D, D, D, 0, m->hid_ld};
-            const bool timed = !m->fused_mlp;
-            if (timed) if (int rc = mark()) return rc;
+            g.tile128 = tile128(m->hidden, D, D);
+            if (int rc = mark(DD_PROF_FC1)) return rc;
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_GELU, s, c->num_cus));
-            if (timed) if (int rc = mark()) return rc;
+            if (int rc = mark(DD_PROF_FC1)) return rc;
         }
         if constexpr (sizeof(T) == 2) {
             if (m->rowlin_fc2) {
@@ -678,7 +725,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     if (m->fused_qa) ra.h_frag = m->hfrag; else ra.h_out = (bf16_t*)h;
                 }
                 rowlin_plan(B, m->N, m->extras, L, m->hidden, ra);
+                if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                 DD_HIP(c, launch_rowlin(ra, s));
+                if (int rc = mark(DD_PROF_ROWLIN)) return rc;
                 MlpFusedArgs fr{};           // the extra-token rows: bias + residual + the K-split slabs in a fixed order (+ their norm1 rows)
                 fr.b2 = w.fc2_b; fr.xres = m->x; fr.out = (bf16_t*)copy; fr.ldo = D; fr.partial = m->mlp_partial;
                 fr.tok_n = ra.tok_n; fr.tok_e = ra.tok_e; fr.tok_l = ra.tok_l; fr.n_extra = ra.n_extra; fr.tiles_left = ra.tiles_extra;
@@ -694,7 +743,9 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             if (m->splitk) {     // mlp.fc2 as split-K halves; x += bias + slabs, the bf16 copy and (in- / mid-blocks) the next block's norm1 in the row pass
                 GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, nullptr, nullptr, nullptr, M, D, m->hidden, m->hidden, m->hid_ld, m->hid_ld, D};
                 g.partial = m->mlp_partial; g.splits = 2;
+                if (int rc = mark(DD_PROF_SPLITK)) return rc;
                 DD_HIP(c, launch_gemm_splitk(g, s, c->num_cus));
+                if (int rc = mark(DD_PROF_SPLITK)) return rc;
                 const bool ln_next = bi + 1 < nb && bi + 1 <= m->half_depth;
                 ReduceLnArgs ra{m->x, m->mlp_partial, (long long)M * D, 2, 1, w.fc2_b, (bf16_t*)copy, D,
                                 ln_next ? m->blocks[bi + 1].ln1_g : nullptr, ln_next ? m->blocks[bi + 1].ln1_b : nullptr, (bf16_t*)h,
@@ -708,6 +759,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
         {
             GemmArgs<T> g{hid, nullptr, (const T*)w.fc2_w, w.fc2_b, m->x, copy, M, D, m->hidden, m->hidden,
                           m->hid_ld, m->hid_ld, D};
+            g.tile128 = tile128(D, m->hidden, m->hidden);
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
     }
@@ -800,11 +852,18 @@ int chain_gemm_cus(dd_ctx* c, dd_model* m, int B) {
 // first chained call of a model, intermittently)
 int ensure_chain_ws(dd_ctx* c, dd_model* m, hipStream_t s) {
     if (m->wsarena2) return DD_OK;
-    DD_HIP(c, hipMalloc((void**)&m->wsarena2, m->wsoff.bytes));
-    DD_HIP(c, hipMemsetAsync(m->wsarena2, 0, m->wsoff.bytes, s));
-    bind_ws(m->wsoff, m->wsarena2, m->ws2);
+    m->wsoff2 = ws_layout(m, (m->cfg.max_batch + 1) / 2);     // a chain never runs more than half of max_batch
+    DD_HIP(c, hipMalloc((void**)&m->wsarena2, m->wsoff2.bytes));
+    DD_HIP(c, hipMemsetAsync(m->wsarena2, 0, m->wsoff2.bytes, s));
+    bind_ws(m->wsoff2, m->wsarena2, m->ws2);
     return DD_OK;
 }
+// a failure between the fork and the join of a chained call must not leave the side stream running on the second chain's buffers behind
+// the caller's back: armed after the fork, disarmed by the regular join
+struct SideJoin {
+    dd_ctx* c; bool armed;
+    ~SideJoin() { if (armed && c->side) (void)hipStreamSynchronize(c->side); }
+};
 
 // the model's captured step of kind `which` (0 DDPM, 1 table-driven) for this key: reused, or captured now from enqueue(m)
 template <typename F>
@@ -885,6 +944,7 @@ int dd_ctx_create(int device, dd_ctx** out) {
     if (!c) return DD_ERR_NOMEM;
     c->device = device;
     c->num_cus = device_num_cus();
+    c->base_cus = c->num_cus;
     const Schedule& s = schedule();
     for (int i = 0; i < 1000; ++i) c->coef_host[i] = StepCoef{s.c1[i], s.c2[i], s.sigma[i], s.sigma_beta[i]};
     bool ok = hipMalloc(&c->st, sizeof(StepState)) == hipSuccess && hipMalloc(&c->coef, sizeof(StepCoef) * 1000) == hipSuccess &&
@@ -1223,25 +1283,9 @@ int dd_model_finalize(dd_model* m, int precision) {
     m->norm_g = F(o_ng); m->norm_b = F(o_nb); m->wdec = F(o_wdec); m->bdec = F(o_bd); m->wconv = F(o_wc); m->bconv = F(o_bc);
 
     // ---- activation workspace (HBM-resident for the life of the model)
-    const size_t Mp = (size_t)m->Mp_max;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    // qkv is head-major: B * 3H units of Lp rows x 64 (rows [L, Lp) stay zero: the workspace is zeroed once, below)
-    const size_t qkv_elems = (size_t)m->cfg.max_batch * 3 * D * (size_t)make_head_major(L, m->H).Lp;
-    const size_t o_x = take(Mp * D * 4), o_h = take(Mp * D * es), o_ao = take(Mp * D * es), o_qkv = take(std::max(Mp * 3 * D, qkv_elems) * es);
-    const size_t o_hid = take(Mp * (size_t)m->hid_ld * es), o_xb = take(Mp * D * es);
-    std::vector<size_t> o_sk;
-    for (int i = 0; i < m->half_depth; ++i) o_sk.push_back(take(Mp * D * es));
-    const size_t o_dec = take(Mp * m->pd * 4);
-    const size_t part_bytes = m->fused_mlp ? mlp_fused_partial_bytes(m->cfg.max_batch, m->extras, D, hid)
-                              : m->splitk ? (size_t)2 * m->Mp_max * D * 4
-                              : m->rowlin_fc2 ? std::max(std::max(rowlin_partial_bytes(m->cfg.max_batch, m->extras, hid), rowlin_partial_bytes(m->cfg.max_batch, m->extras, 2 * D)), rowlin_partial_bytes(m->cfg.max_batch, m->extras, D)) : 0;
-    const size_t o_part = take(part_bytes);
-    const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
-    const size_t o_hf = take(m->fused_qa ? (size_t)m->cfg.max_batch * m->N * D * 2 : 0);
-    m->wsoff = WsOffsets{o_x, o_h, o_ao, o_qkv, o_hid, o_xb, o_dec, o_part, o_dump, o_hf, off, o_sk, part_bytes != 0, m->fused_qkv, m->fused_qa};
-    DD_HIP(c, hipMalloc((void**)&m->wsarena, off));
-    DD_HIP(c, hipMemset(m->wsarena, 0, off));
+    m->wsoff = ws_layout(m, m->cfg.max_batch);
+    DD_HIP(c, hipMalloc((void**)&m->wsarena, m->wsoff.bytes));
+    DD_HIP(c, hipMemset(m->wsarena, 0, m->wsoff.bytes));
     DD_HIP(c, hipStreamSynchronize(nullptr));    // (callers run the model on non-blocking streams, which a null-stream memset does not order itself before)
     {
         WsPtrs w;
@@ -1249,7 +1293,7 @@ int dd_model_finalize(dd_model* m, int precision) {
         m->x = w.x; m->h = w.h; m->ao = w.ao; m->qkv = w.qkv; m->hid = w.hid; m->xb = w.xb; m->dec = w.dec; m->skips = w.skips;
         m->mlp_partial = w.mlp_partial; m->qkv_dump = w.qkv_dump; m->hfrag = w.hfrag;
     }
-    m->mlp_partial_bytes = part_bytes;
+    m->mlp_partial_bytes = m->wsoff.part_bytes;
 
     // host copies are no longer needed
     for (auto& kv : m->params) { std::vector<float>().swap(kv.second.data); }
@@ -1436,6 +1480,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
         DD_HIP(c, hipEventRecord(c->ev_fork, s));                 // the side stream starts behind the staging copies and the state
         DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
+    SideJoin side_join{c, chained};
     DD_HIP(c, hipEventRecord(c->ev[0], s));
     bool marked = false;
     dd_model* cur = a->first;
@@ -1456,6 +1501,7 @@ int dd_sample(dd_ctx* c, const dd_sample_args* a, void* stream) {
     if (chained) {
         DD_HIP(c, hipEventRecord(c->ev_join, c->side));
         DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        side_join.armed = false;
     }
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));
@@ -1529,6 +1575,7 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
         DD_HIP(c, hipEventRecord(c->ev_fork, s));
         DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
+    SideJoin side_join{c, chained};
     DD_HIP(c, hipEventRecord(c->ev[0], s));
     bool marked = false;
     dd_model* cur = a->first;
@@ -1549,6 +1596,7 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
     if (chained) {
         DD_HIP(c, hipEventRecord(c->ev_join, c->side));
         DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        side_join.armed = false;
     }
     if (!marked) DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));
@@ -1624,9 +1672,24 @@ int dd_sample_early_exit(dd_ctx* c, const dd_ee_sample_args* a, void* stream) {
 long long dd_dev_graph_captures(dd_ctx* c) { return c ? c->graph_captures : -1; }
 int dd_dev_last_sample_chains(dd_ctx* c) { return c ? c->last_chains : -1; }
 
+int dd_dev_poison_workspaces(dd_ctx* c, dd_model* m, void* stream) {
+    if (!c || !m || m->ctx != c || !m->finalized) return DD_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = ensure_chain_ws(c, m, s)) return rc;
+    DD_HIP(c, hipMemsetAsync(m->wsarena, 0xFF, m->wsoff.bytes, s));
+    DD_HIP(c, hipMemsetAsync(m->wsarena2, 0xFF, m->wsoff2.bytes, s));
+    return DD_OK;
+}
+
 int dd_dev_set_flags(dd_ctx* c, unsigned flags) {
     if (!c) return DD_ERR_INVALID;
     c->dev_flags = flags;
+    return DD_OK;
+}
+
+int dd_profile_select(dd_ctx* c, int kind) {
+    if (!c || kind < DD_PROF_DOMINANT || kind > DD_PROF_SPLITK) return DD_ERR_INVALID;
+    c->prof_kind = kind;
     return DD_OK;
 }
 
@@ -1679,8 +1742,12 @@ int dd_profile_steps_chained(dd_ctx* c, dd_model* m, float* x_dev, const int64_t
     if ((rc = ensure_chain_ws(c, m, s))) return rc;
     const int B0 = B / 2, B1 = B - B0;
     const size_t chw = (size_t)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+    // (the persistent GEMM grids of both chains sized as dd_sample sizes them: halved for a large GEMM-path batch)
+    struct CusGuard { dd_ctx* c; int saved; ~CusGuard() { c->num_cus = saved; } } cus_guard{c, c->num_cus};
+    c->num_cus = chain_gemm_cus(c, m, B);
     DD_HIP(c, hipEventRecord(c->ev_fork, s));
     DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    SideJoin side_join{c, true};
     m->time_fc1 = true;
     m->fc1_used = 0;
     for (int i = 0; i < steps && !rc; ++i) {
@@ -1698,6 +1765,7 @@ int dd_profile_steps_chained(dd_ctx* c, dd_model* m, float* x_dev, const int64_t
     if (rc) return rc;
     DD_HIP(c, hipEventRecord(c->ev_join, c->side));
     DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    side_join.armed = false;
     DD_HIP(c, hipStreamSynchronize(s));
     double total = 0.0;
     for (size_t i = 0; i + 1 < m->fc1_used; i += 2) {
@@ -1906,6 +1974,7 @@ int dd_set_num_cus(dd_ctx* c, int n) {
     if (!c) return DD_ERR_INVALID;
     if (n < 8) return fail(c, DD_ERR_INVALID, "need at least 8 CUs");
     c->num_cus = n / 8 * 8;      // the persistent kernels deal tiles to workgroups in groups of 8 (one per XCD)
+    c->base_cus = c->num_cus;
     return DD_OK;
 }
 

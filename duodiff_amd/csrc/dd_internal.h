@@ -93,11 +93,15 @@ struct GemmArgs {
     HeadMajor hm;      // hm.L != 0: `out` is written head-major (the qkv Linear); N % 64 == 0
     float* partial = nullptr;   // launch_gemm_splitk: fp32 slabs [splits][M][N]
     int splits = 0;
+    int tile128 = -1;           // bf16 launch_gemm: 1 = the 128 x 128 kernel, 0 = the 256 x 256 kernel where the shape fits it, -1 = decided from THIS call's shape
+                                // (gemm_prefers_128).  The model's launches pass the decision made for its max_batch, so that a row's kernel never
+                                // depends on the batch of a call (the two half-batch chains of dd_sample must compute what the whole batch computes)
 };
 
 // num_cus: CU count the persistent bf16 grid is sized for (per context; a multiple of 8)
 template <typename T> hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int num_cus);
 bool plan_rows_256(int M, int N, int K, int num_cus, int* q, int* e);
+bool gemm_prefers_128(int M, int N, int K, int K1, int num_cus);   // the 256 x 256 tiles of this shape would leave half of the CUs without one
 bool gemm_splitk_supported(int M, int N, int K, int K1, int splits);
 hipError_t launch_gemm_splitk(const GemmArgs<bf16_t>& a, hipStream_t s, int num_cus);
 int device_num_cus();

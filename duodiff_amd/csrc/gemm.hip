@@ -758,6 +758,14 @@ hipError_t launch_gemm_splitk(const GemmArgs<bf16_t>& a, hipStream_t s, int num_
     return launch_256(a, EPI_PARTIAL, p, cus, s);
 }
 
+// a launch whose 256 x 256 tiles would leave half of the grid's CUs without one (ImageNet-256 latents, B = 32: the N = 1024 Linears have
+// 32 x 4 tiles) is better off with the 128 x 128 kernel: four times the tiles, two workgroups per CU
+bool gemm_prefers_128(int M, int N, int K, int K1, int num_cus) {
+    Part256 p;
+    const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
+    return plan256(M, N, K, K1, cus, p) && (long long)p.q * (N / 256) * 2 <= cus;
+}
+
 // bf16: the persistent 256x256 kernel where the shape fits it, else the generic 128x128 kernel; fp32 (parity mode, exact
 // f32 MFMA): generic kernel.  num_cus sizes the persistent grid (per context: dd_set_num_cus).
 template <typename T>
@@ -772,9 +780,8 @@ hipError_t launch_gemm(const GemmArgs<T>& a, int epilogue, hipStream_t s, int nu
         Part256 p;
         const int cus = num_cus >= 8 ? num_cus / 8 * 8 : 256;
         if ((a.K1 == a.K || a.lda == a.lda2) && plan256(a.M, a.N, a.K, a.K1, cus, p)) {
-            // a launch whose 256 x 256 tiles would leave half of the grid's CUs without one (ImageNet-256 latents, B = 32: the N = 1024
-            // Linears have 32 x 4 tiles) takes the 128 x 128 kernel instead: four times the tiles, two workgroups per CU
-            if ((long long)p.q * (a.N / 256) * 2 <= cus && !a.hm.L) return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
+            const bool small = a.tile128 < 0 ? (long long)p.q * (a.N / 256) * 2 <= cus : a.tile128 == 1;     // (gemm_prefers_128; the caller's decision if it made one)
+            if (small && !a.hm.L) return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);
             return launch_256(a, epilogue, p, cus, s);
         }
         return launch_cfg<T, 128, 128, 2, 2, 2>(a, epilogue, s);   // shapes the 256x256 kernel does not take (small N, tiny M)

@@ -210,10 +210,10 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     float cshift = 0.f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        if (a.set_x) {   // no residual: the strip (leftover ring bytes) is zeroed so that the 0 factor meets finite values
+        if (a.set_x || part_tile) {   // no residual (skip_linear; a slab tile: the reduce launch adds x): the strip (leftover ring bytes) is zeroed so that the 0 factor meets finite values
 #pragma unroll
             for (int j = 0; j < 32; ++j) *reinterpret_cast<f32x4*>(strip + r32 * kPitch + (h * 32 + j) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {   // (a slab tile fetches 32 residual rows from its first token on, clamped to the last row -- finite values that its 0 factor drops)
+        } else {
             const char* src = reinterpret_cast<const char*>(a.xres + 256 * p) + lane * 16;
             for (int i = 0; i < nvalid; ++i) {
                 const long long ri = row0w + i < rows_all ? row0w + i : rows_all - 1;

@@ -223,17 +223,23 @@ class Model:
                                                    _stream_ptr(stream)))
         return x
 
-    def profile_steps(self, x, t_start=699, steps=10, y=None, stream=None):
-        """Average ms of the fc1 GEMM measured in context (event pairs around every launch of `steps` eager steps)."""
+    PROFILE_KINDS = {"dominant": L.DD_PROF_DOMINANT, "block_tail": L.DD_PROF_BLOCK_TAIL, "fc1": L.DD_PROF_FC1, "rowlin": L.DD_PROF_ROWLIN,
+                     "qkv_attention": L.DD_PROF_QKV_ATTENTION, "splitk": L.DD_PROF_SPLITK}
+
+    def profile_steps(self, x, t_start=699, steps=10, y=None, stream=None, kind="dominant"):
+        """Average ms per launch of one kernel family measured in context (event pairs around every such launch of `steps` eager steps);
+        kind: "dominant" (the fused block tail where the model has one, else the fc1 GEMM) or one of PROFILE_KINDS."""
         ms, n = C.c_float(), C.c_int()
+        self.ctx.check(self.ctx.lib.dd_profile_select(self.ctx.handle, self.PROFILE_KINDS[kind]))
         self.ctx.check(self.ctx.lib.dd_profile_steps(self.ctx.handle, self.handle, _ptr(x), _ptr(y), int(t_start), int(steps),
                                                      x.shape[0], _stream_ptr(stream), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def profile_steps_chained(self, x, t_start=699, steps=10, y=None, stream=None):
+    def profile_steps_chained(self, x, t_start=699, steps=10, y=None, stream=None, kind="dominant"):
         """The same with the batch split into dd_sample's two half-batch chains (the caller's stream + the context's side stream):
         average ms of a half-batch launch of the dominant kernel while the other chain runs beside it."""
         ms, n = C.c_float(), C.c_int()
+        self.ctx.check(self.ctx.lib.dd_profile_select(self.ctx.handle, self.PROFILE_KINDS[kind]))
         self.ctx.check(self.ctx.lib.dd_profile_steps_chained(self.ctx.handle, self.handle, _ptr(x), _ptr(y), int(t_start), int(steps),
                                                              x.shape[0], _stream_ptr(stream), C.byref(ms), C.byref(n)))
         return ms.value, n.value

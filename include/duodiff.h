@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 4
+#define DD_ABI_VERSION 5
 
 typedef struct dd_ctx dd_ctx;
 typedef struct dd_model dd_model;
@@ -260,6 +260,21 @@ int dd_bench_gemm(dd_ctx* ctx, dd_model* m, int B, int iters, void* stream,
  * and returns the average milliseconds per launch: what rocprofv3 --kernel-trace averages for that kernel. */
 int dd_profile_steps(dd_ctx* ctx, dd_model* m, float* x_dev, const int64_t* y_dev, int t_start, int steps, int B,
                      void* stream, float* fc1_ms_out, int* launches_out);
+/* Which launches the two profile entries bracket (default DD_PROF_DOMINANT; the choice stays with the context).  bench.py selects the
+ * kernel with the largest total time in the workload's committed rocprofv3 kernel table (profiles/rNN/kernel_stats*.csv):
+ *   DD_PROF_DOMINANT       the fused block tail where the model has one, else the mlp.fc1 GEMM (the round-1..4 behaviour)
+ *   DD_PROF_BLOCK_TAIL     mlp_fused_kernel launches only
+ *   DD_PROF_FC1            the mlp.fc1 GEMM (gemm256_kernel<bias + GELU>)
+ *   DD_PROF_ROWLIN         every row-resident Linear launch (embed_dim 768: attn.proj, mlp.fc2, skip_linear -- one kernel, rowlin768_kernel)
+ *   DD_PROF_QKV_ATTENTION  the attn.qkv + attention launch (qkv_attention_kernel), or the plain attention launch
+ *   DD_PROF_SPLITK         every split-K GEMM launch (small-batch embed_dim 1024: attn.proj, mlp.fc2, skip_linear -- gemm256_kernel<partial>) */
+#define DD_PROF_DOMINANT 0
+#define DD_PROF_BLOCK_TAIL 1
+#define DD_PROF_FC1 2
+#define DD_PROF_ROWLIN 3
+#define DD_PROF_QKV_ATTENTION 4
+#define DD_PROF_SPLITK 5
+int dd_profile_select(dd_ctx* ctx, int kind);
 /* The same measurement for the way dd_sample runs an even batch >= 32: TWO half-batch chains (images [0, B/2) on `stream`, the rest on
  * the context's side stream), enqueued eagerly step by step, an event pair around every launch of the dominant kernel in both
  * chains -- each timed launch covers B/2 images and overlaps the other chain's kernels as in the timed loop. */

@@ -63,6 +63,11 @@ int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
  * same shape must not capture again). */
 long long dd_dev_graph_captures(dd_ctx* ctx);
 
+/* Fill every activation buffer of model m -- the main workspace and the second chain's (allocated here if dd_sample has not yet) -- with
+ * 0xFF bytes (NaN as bf16 and as fp32) ON `stream`.  Tests: a run that follows must equal a run on a fresh model bit for bit, i.e. no kernel
+ * may depend on what a buffer held before the launches of the call wrote it (zero-initialised padding, stale slabs). */
+int dd_dev_poison_workspaces(dd_ctx* ctx, dd_model* m, void* stream);
+
 /* Number of chains the last dd_sample call on this context ran (1, or 2 half-batch chains on two streams). */
 int dd_dev_last_sample_chains(dd_ctx* ctx);
 

@@ -28,18 +28,20 @@ def eps_tol(precision, ref, full_size=False):
     """max-abs bound on eps: absolute in the exact-fp32 mode; in bf16 mode a LOOSE guard relative to the spread of the reference
     output -- 3e-2 sigma for the tiny fixtures, 5e-2 sigma for the full-size cases (observed 1.4 .. 3.4e-2 sigma: the maximum of a
     1536-value slice moves by +-5 % with every change of accumulation order in a kernel, so it is not the regression gate).
-    The gate is the rms error, per config: EPS_RMS_OBSERVED x 1.25."""
+    The gate is the rms error against the error model of eps_rms_bound (fixed margin, no per-config constants)."""
     return 1e-4 if precision == "fp32" else (5e-2 if full_size else 3e-2) * float(np.asarray(ref, np.float64).std())
 
 
-# bf16 engine vs the reference, full-size configs, B = 2: rms(eps - ref) / sigma(ref) as measured on MI355X (profiles/r04/parity_numbers.txt;
-# an error model for scale: every block rounds ~6 GEMM operands to bf16, relative rms 2^-9 / sqrt(3) each, adding in quadrature over
-# the depth: 1.1e-3 sqrt(6 depth) = 4.8e-3 (depth 3) .. 1.2e-2 (depth 21)).  The test allows observed x 1.25.
-EPS_RMS_OBSERVED = {
-    "uvit_cifar10": 9.2e-3, "uvit_cifar10_3": 4.6e-3, "uvit_celeba": 5.6e-3, "uvit_celeba_3": 5.1e-3,
-    "uvit_imagenet64": 6.9e-3, "uvit_imagenet64_3": 5.5e-3, "uvit_imagenet256": 5.3e-3, "uvit_imagenet256_3": 4.8e-3,
-}
-EPS_RMS_MARGIN = 1.25
+# bf16 engine vs the reference: the gate on rms(eps - ref) / sigma(ref) is an ERROR MODEL, not a fit to the last run.  Every block rounds
+# ~6 GEMM operands to bf16 (norm1 rows, the attention output, norm2 rows, the GELU'd hidden rows, the long-skip copy, P of the attention
+# core), each with relative rms 2^-9 / sqrt(3) (uniform rounding error of an 8-bit significand), and the roundings of the `depth` blocks
+# add in quadrature on a residual stream of spread ~sigma:  model = 2^-9 / sqrt(3) * sqrt(6 depth)  =  4.8e-3 (depth 3) .. 9.9e-3 (13)
+# .. 1.27e-2 (21).  Observed on MI355X (profiles/r05/parity_numbers.txt): 0.47 .. 0.96 of the model.  The bound is the model x 1.5, fixed.
+EPS_RMS_MODEL_MARGIN = 1.5
+
+
+def eps_rms_bound(depth):
+    return EPS_RMS_MODEL_MARGIN * 2.0 ** -9 / np.sqrt(3.0) * np.sqrt(6.0 * depth)
 
 
 def _uvit(cfg, seed, precision, max_batch=None):
@@ -91,7 +93,7 @@ def test_forward_full_size_vs_reference(golden, name, precision):
     print(f"{name} {precision}: max|eps - ref| (slice) = {err:.3e}, rms {rms:.3e} ({rms / sigma:.2e} sigma); std {eps.std():.4f} vs {st[1]:.4f}")
     assert err <= eps_tol(precision, fx["eps_slice"], full_size=True)
     if precision == "bf16":
-        assert rms <= EPS_RMS_MARGIN * EPS_RMS_OBSERVED[name] * sigma, f"rms {rms / sigma:.3e} sigma vs observed {EPS_RMS_OBSERVED[name]:.1e} x {EPS_RMS_MARGIN}"
+        assert rms <= eps_rms_bound(mp.depth) * sigma, f"rms {rms / sigma:.3e} sigma vs the error model's bound {eps_rms_bound(mp.depth):.2e} (depth {mp.depth})"
     assert abs(eps.std(dtype=np.float64) - st[1]) <= (1e-4 if precision == "fp32" else 5e-3)
     assert abs(eps.astype(np.float64).sum() - float(fx["checksum"])) <= (1e-5 if precision == "fp32" else 2e-3) * eps.size
 
@@ -233,6 +235,78 @@ def test_half_batch_chains_equal_the_single_chain(case):
     assert outs["chained"][1] == 4 and outs["single"][1] == 2, f"graph captures: {outs['chained'][1]} chained, {outs['single'][1]} single"
     assert torch.isfinite(outs["single"][0]).all() and not torch.equal(outs["single"][0], x0)
     assert torch.equal(outs["chained"][0], outs["single"][0]), "two half-batch chains differ from the single chain"
+
+
+@pytest.mark.parametrize("case", ["tiny_forced", "tiny_cond_forced", "celeba_default", "width768_forced", "width1024_forced", "tiny_fp32_single"])
+def test_no_kernel_depends_on_stale_workspace_bytes(case):
+    """The class of bug behind the round-4 chain-workspace race: kernels that read bytes of the activation workspace which nothing in the
+    call wrote (zero-initialised padding, slabs of an earlier call).  Both chains' workspaces are filled with NaN bytes ON THE LAUNCH
+    STREAM right before a model pair's first dd_sample (dd_dev_poison_workspaces allocates the second chain's workspace first, so the
+    call does not zero it again); the samples must equal those of fresh, zero-initialised models bit for bit."""
+    from duodiff_amd import _lib as L
+    from duodiff_amd.engine import sample_loop
+    prec, flags = "bf16", L.DD_DEV_FORCE_CHAINS
+    if case == "celeba_default":
+        B, S, C_, steps, tsw, flags = 128, 64, 3, 4, 2, 0
+        cfg_s, cfg_f = load_config(REPO / "configs" / "uvit_celeba_3.yaml"), load_config(REPO / "configs" / "uvit_celeba.yaml")
+    elif case in ("width768_forced", "width1024_forced"):     # the row-resident / split-K launches and their slabs, one and two extra tokens
+        B, S, C_, steps, tsw = 4, 32, 3, 3, 1
+        D = 768 if case == "width768_forced" else 1024
+        base = dict(img_size=32, patch_size=2, in_chans=3, embed_dim=D, num_heads=D // 64, mlp_ratio=4, qkv_bias=False, mlp_time_embed=False,
+                    num_classes=10 if D == 768 else -1, normalize_timesteps=True)
+        cfg_s, cfg_f = dict(base, depth=1), dict(base, depth=3)
+    else:
+        B, S, C_, steps, tsw = 6, 8, 3, 8, 3
+        nc = 10 if case == "tiny_cond_forced" else -1
+        cfg_s, cfg_f = dict(TINY, depth=1, num_classes=nc), dict(TINY, depth=3, num_classes=nc)
+        if case == "tiny_fp32_single":
+            prec, flags = "fp32", L.DD_DEV_NO_CHAINS
+    x0 = torch.randn(B, C_, S, S, generator=torch.Generator().manual_seed(14)).cuda()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for poison in (False, True):
+        m_s, _ = _uvit(cfg_s, 131, prec, max_batch=B)
+        m_f, mp_f = _uvit(cfg_f, 132, prec, max_batch=B)
+        es, ef = m_s.engine_model(B), m_f.engine_model(B)
+        ctx = es.ctx
+        ncls = int(mp_f.num_classes)
+        y = torch.randint(0, ncls, (B,), generator=torch.Generator().manual_seed(15)).cuda() if ncls > 0 else None
+        try:
+            ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+            with torch.cuda.stream(stream):
+                if poison:
+                    for e in (es, ef):
+                        ctx.check(ctx.lib.dd_dev_poison_workspaces(ctx.handle, e.handle, stream.cuda_stream))
+                x = x0.clone()
+                sample_loop(ctx, es, ef, x, t_switch=tsw, t_start=999, t_end=1000 - steps, y=y, seed=19, noise="philox", use_graph=True, stream=stream)
+                stream.synchronize()
+            outs.append((x.clone(), ctx.lib.dd_dev_last_sample_chains(ctx.handle)))
+        finally:
+            ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+        del es, ef, m_s, m_f
+    assert outs[0][1] == outs[1][1] == (1 if flags == L.DD_DEV_NO_CHAINS else 2)
+    assert torch.isfinite(outs[0][0]).all() and not torch.equal(outs[0][0], x0)
+    bad = (outs[0][0] != outs[1][0]).flatten(1).any(1).nonzero().flatten().tolist()
+    assert not bad, f"{case}: images {bad[:8]}... differ after the workspaces were poisoned (a kernel reads bytes no launch of the call wrote)"
+
+
+def test_profile_steps_chained_counts_and_grid():
+    """dd_profile_steps_chained (bench.py's `chained` roofline leg) brackets every launch of the selected kernel in BOTH chains:
+    2 x steps x depth event pairs for the block tail, and it runs on the chain-sized GEMM grids dd_sample uses."""
+    cfg = load_config(REPO / "configs" / "uvit_celeba_3.yaml")
+    m, mp = _uvit(cfg, 7, "bf16", max_batch=64)
+    em = m.engine_model(64)
+    x = torch.randn(64, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        ms1, n1 = em.profile_steps(x.clone(), t_start=699, steps=3, stream=stream)
+        ms2, n2 = em.profile_steps_chained(x.clone(), t_start=699, steps=3, stream=stream)
+        ms3, n3 = em.profile_steps(x.clone(), t_start=699, steps=2, stream=stream, kind="qkv_attention")
+        ms4, n4 = em.profile_steps(x.clone(), t_start=699, steps=2, stream=stream, kind="rowlin")     # (no such launch in this model)
+    assert n1 == 3 * mp.depth and n2 == 2 * 3 * mp.depth and n3 == 2 * mp.depth and n4 == 0
+    assert 0 < ms2 < ms1 * 1.5 and ms3 > 0 and ms4 == 0
 
 
 def test_half_batch_chains_in_the_table_driven_loops():

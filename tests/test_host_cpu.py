@@ -176,3 +176,26 @@ def test_gemm_row_partition_covers_every_row_once_and_fills_the_cus():
     # ImageNet-64 B=256, L=258: 2 tail rows per tile instead of 258 M-tiles
     assert plan(256 * 258, 768, 768) == (256, 2)
     assert plan(100, 512, 512) is None and plan(1024, 48, 512) is None      # tiny M / narrow N fall back
+
+
+def test_bench_roofline_leg_follows_the_committed_kernel_table():
+    """bench.py times the kernel that rocprofv3's committed table of the workload ranks first: the block tail on the
+    headline workload, the row-resident Linear on ImageNet-64, the split-K GEMM on the ImageNet-256 latents -- and every family it can
+    select has a FLOP / byte model and a DD_PROF_* kind the library accepts."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from duodiff_amd.engine import Model
+    want = {"celeba": "block_tail", "imagenet64": "rowlin", "imagenet256": "splitk"}
+    for w, (_, _, cfg_f, B, _) in b.WORKLOADS.items():
+        mp = ModelParams.from_dict(load_config(REPO / "configs" / f"{cfg_f}.yaml"))
+        shares = b.kernel_shares(w)
+        assert shares and shares[0][0] == want[w], (w, shares)
+        assert abs(sum(s for _, _, s in shares)) <= 1.0 + 1e-9
+        for kind, frag, share in shares:
+            fl, by, pmc, name, n = b.family_model(kind, mp, B)
+            assert fl > 0 and by > 0 and n > 0 and frag in pmc + name
+            assert kind in Model.PROFILE_KINDS and 0 < b.cu_share_half_batch(kind, mp, B) <= 1.0
+    lib = _lib.load()
+    assert lib.dd_profile_select(None, 0) == _lib.DD_ERR_INVALID      # (a null context is refused: the symbol exists and checks its arguments)

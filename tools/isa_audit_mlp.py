@@ -11,7 +11,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
-SRC = REPO / "duodiff_amd" / "csrc" / "mlp_fused.hip"
+SRC = Path(sys.argv[1]).resolve() if len(sys.argv) > 1 else REPO / "duodiff_amd" / "csrc" / "mlp_fused.hip"   # (a variant copy: tools/build_variant.py --csrc)
 
 
 def main():
