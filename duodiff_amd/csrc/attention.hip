@@ -41,13 +41,22 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// XOR swizzles of the bf16 K / V images in LDS (128-byte rows of eight 16-byte chunks; chunk ch of row r is stored at chunk ch ^ swz(r)).
+// Each serves the image's READ pattern and its WRITE pattern without a bank conflict (MI355X_MICROARCH.md, LDS: a ds_read_b128 serves 4 groups of
+// 16 lanes over 64 banks = two rows' worth, a ds_write_b128 8 groups of 8 contiguous lanes over 32 banks = one row's worth):
+//   K  read: a lane group holds 8 even + 8 odd rows with 8 different (r >> 1) & 7 each; write (qkv_attention_kernel's epilogue): 8 consecutive
+//            rows -- (r >> 1) & 7 alone gives them only 4 different chunks (2-way), the r & 1 bit in the top position makes it 8;
+//   V  read: ds_read_b64_tr_b16 of a 4-row block by 32 lanes, rows r & 3 = 0..3 at a fixed (r >> 2) & 1; write: 8 consecutive rows.
+__device__ __forceinline__ int k_swz(int r) { return ((r >> 1) & 7) ^ ((r & 1) << 2); }
+__device__ __forceinline__ int v_swz(int r) { return (2 * (r & 3)) ^ ((r >> 2) & 1); }
+
 template <typename T> struct AttnLayout;
 template <> struct AttnLayout<bf16_t> {
-    // K rows are 128 B, LDS-DMA'd linearly (a 1 KB piece = 8 rows); 16-byte chunk ch of row r sits at slot ch ^ ((r >> 1) & 7)
+    // K rows are 128 B, LDS-DMA'd linearly (a 1 KB piece = 8 rows); 16-byte chunk ch of row r sits at slot ch ^ k_swz(r)
     // (the swizzle is applied to the SOURCE address of the DMA and again on the read: conflict-free ds_read_b128 fragments,
     // the same image gemm.hip uses)
     static constexpr int kRowK = 128;
-    // V stays ROW-major ([key][64 d], 128-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ 2 (r & 3)): LDS-DMA'd like
+    // V stays ROW-major ([key][64 d], 128-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ v_swz(r)): LDS-DMA'd like
     // K, and read as the V^T MFMA operand with the transposing ds_read_b64_tr_b16 (a block of 4 keys x
     // 16 d per 16 lanes; the XOR puts the four rows of a block into the four bank quarters: conflict-free).  The first
     // version wrote V transposed with 4-byte scattered LDS writes -- 12 of the kernel's 47 us.
@@ -81,7 +90,7 @@ __device__ __forceinline__ void attend_tiles(const char* Ks, const char* Vt, int
         // hides under them (the plain read -> wait -> MFMA chain spent most of a chunk in s_waitcnt lgkmcnt)
         auto load_k = [&](int t, bf16x8 (&kf)[4]) {
             const char* kr = Ks + (t * 32 + r32) * Lay::kRowK;
-            const int sw = (r32 >> 1) & 7;                         // (32 t contributes 0 to (row >> 1) & 7)
+            const int sw = k_swz(r32);                             // (32 t contributes nothing to the swizzle bits)
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 // KPERM: the 64 d of a K row sit in accumulator order (qkv_attention_kernel writes them from its accumulators):
@@ -185,7 +194,8 @@ __device__ __forceinline__ void attend_tiles(const char* Ks, const char* Vt, int
         // lane ends up with V[those 4 keys][dt * 32 + (lane & 31)] -- the V^T fragment the MFMA wants.
         const int tq = (lane >> 2) & 3, tp = lane & 3, dhalf = (lane >> 4) & 1;
         const char* vb0 = Vt + (4 * half + tq) * Lay::kRowV + 8 * (tp & 1);
-        const char* vbd[2] = {vb0 + (((2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4), vb0 + (((4 + 2 * dhalf + (tp >> 1)) ^ (2 * tq)) << 4)};
+        const int vsw = v_swz(4 * half + tq);                      // (the rows this lane addresses differ from 4 half + tq by multiples of 8)
+        const char* vbd[2] = {vb0 + (((2 * dhalf + (tp >> 1)) ^ vsw) << 4), vb0 + (((4 + 2 * dhalf + (tp >> 1)) ^ vsw) << 4)};
         typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
         auto load_v = [&](int t, VF& f) {
 #pragma unroll
@@ -286,8 +296,8 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
     // ---- stage K (row-major) and V (transposed) of this head; zero the padded keys
     if constexpr (sizeof(T) == 2) {
         // LDS-DMA, 1 KB pieces of 8 rows x 128 B: piece p of K, then piece p of V; lane = (row 8p + (lane >> 3), slot lane & 7)
-        // fetches the chunk that belongs in its slot (source-side swizzle).  Rows [L, Lp) of the unit are zeros in HBM (never
-        // written); rows [Lp, 32 nkt) of the LDS images are zeroed here (V: 0 x garbage must not be NaN).
+        // fetches the chunk that belongs in its slot (source-side swizzle).  Rows [L, Lp) of the images receive a copy of row L - 1 (masked keys);
+        // rows [Lp, 32 nkt) of the LDS images are zeroed here (V: 0 x garbage must not be NaN).
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int np = Lp >> 3;                                        // pieces per operand (33 for L = 257 / 258)
@@ -300,8 +310,10 @@ attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int L, i
             if (p2 < 2 * np) {
                 const bool isv = p2 >= np;
                 const int p = isv ? p2 - np : p2, r = 8 * p + lr;
-                const int ch = isv ? (slot ^ (2 * (r & 3))) : (slot ^ ((r >> 1) & 7));
-                const T* src = (isv ? vbase : kbase) + (long long)r * kHD + ch * 8;
+                const int ch = isv ? (slot ^ v_swz(r)) : (slot ^ k_swz(r));
+                // (rows [L, Lp) of a unit are never written by the qkv Linear: those lanes fetch the last valid row instead -- finite values for keys
+                // that the softmax masks; nothing may depend on what the workspace held before this call)
+                const T* src = (isv ? vbase : kbase) + (long long)(r < L ? r : L - 1) * kHD + ch * 8;
                 char* dst = (isv ? Vt : Ks) + p * 1024;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
             }
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     // ---- q stays in registers (its accumulators, packed to bf16, are the B fragments of S^T = K Q^T in accumulator k order), k and v
     // go to the LDS images the attention core reads (K rows in that same accumulator order, V row-major)
     f32x4 qcur[4];
-    const int swk = (row >> 1) & 7, swv = 2 * (row & 3);
+    const int swk = k_swz(row), swv = v_swz(row);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         if (a.bias) {
@@ -666,10 +678,14 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
         } else if (j < 4) {     // k: the same order, chunk 4 T + 2 half + eh of the row
             *reinterpret_cast<uint4*>(Ks + row * 128 + (((4 * T + 2 * half) ^ swk) << 4)) = uint4{pk[0], pk[1], pk[2], pk[3]};
             *reinterpret_cast<uint4*>(Ks + row * 128 + (((4 * T + 2 * half + 1) ^ swk) << 4)) = uint4{pk[4], pk[5], pk[6], pk[7]};
-        } else {                // v: row-major, register quad g = d 32 T + 8 g + 4 half .. + 3
+        } else {                // v: row-major, register quad g = d 32 T + 8 g + 4 half .. + 3; v_permlane32_swap pairs the lane halves into whole 16-byte
+                                // chunks (lane half 0: chunk 4 T + gp, half 1: chunk 4 T + gp + 1), so that 8 consecutive rows hit 8 different chunks
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<uint2*>(Vt + row * 128 + (((4 * T + g) ^ swv) << 4) + 8 * half) = uint2{pk[2 * g], pk[2 * g + 1]};
+            for (int gp = 0; gp < 4; gp += 2) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp], pk[2 * gp + 2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp + 1], pk[2 * gp + 3], false, false);
+                *reinterpret_cast<uint4*>(Vt + row * 128 + (((4 * T + gp + half) ^ swv) << 4)) = uint4{s0[0], s1[0], s0[1], s1[1]};
+            }
         }
     }
     __syncthreads();     // every wave's partial sums of the extra rows are in px
@@ -684,9 +700,9 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
             *reinterpret_cast<bf16_t*>(qxl + e * 128 + d * 2) = vb;
         } else if (j < 4) {      // K row in accumulator order (KPERM): d = 32 T + (ae & 3) + 8 (ae >> 2) + 4 hf -> chunk 4 T + 2 hf + (ae >> 3), element ae & 7
             const int T = d >> 5, dd = d & 31, hf = (dd >> 2) & 1, ae = (dd & 3) + 4 * (dd >> 3);
-            *reinterpret_cast<bf16_t*>(Ks + r * 128 + (((4 * T + 2 * hf + (ae >> 3)) ^ ((r >> 1) & 7)) << 4) + (ae & 7) * 2) = vb;
+            *reinterpret_cast<bf16_t*>(Ks + r * 128 + (((4 * T + 2 * hf + (ae >> 3)) ^ k_swz(r)) << 4) + (ae & 7) * 2) = vb;
         } else {
-            *reinterpret_cast<bf16_t*>(Vt + r * 128 + (((d >> 3) ^ (2 * (r & 3))) << 4) + (d & 7) * 2) = vb;
+            *reinterpret_cast<bf16_t*>(Vt + r * 128 + (((d >> 3) ^ v_swz(r)) << 4) + (d & 7) * 2) = vb;
         }
     }
     __syncthreads();     // the K / V images are complete

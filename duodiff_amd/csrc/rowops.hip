@@ -575,7 +575,9 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
 // instead of up to nine times.  Same arithmetic, same rounding order.
 __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
 #pragma clang fp contract(off)
-    __shared__ float u[4][18][19];
+    // (row pitch 48 = 16 mod 32 words: the two 16-pixel rows a 32-lane group reads fall into disjoint bank halves; pitch 19 gave every tap read
+    // a 2-way conflict on three banks -- 1.7 conflict cycles per LDS-active cycle in the round 2-4 profiles, for a kernel that is latency, not LDS)
+    __shared__ float u[4][18][48];
     const int S = a.S, P = a.P, C = a.C, g = S / P, pd = P * P * C;
     const int tiles = (S + 15) / 16;
     const int b = blockIdx.x / (tiles * tiles), ty = (blockIdx.x / tiles) % tiles, tx = blockIdx.x % tiles;
