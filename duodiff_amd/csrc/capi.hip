@@ -53,6 +53,7 @@ struct dd_ctx {
     AffineRow* atab = nullptr;
     size_t atab_rows = 0;
     std::vector<AffineRow> atab_host;
+    bool ee_inline = false;      // early-exit heads / probes stay on the launch stream (set while the two chains of dd_sample_early_exit are enqueued: `side` is a chain's stream then)
     int prof_kind = 0;           // dd_profile_select: which launches dd_profile_steps brackets (DD_PROF_*)
     unsigned dev_flags = 0;      // dd_dev_set_flags (include/duodiff_dev.h): kernel-variant switches of the development harness
 };
@@ -139,12 +140,13 @@ struct dd_model {
     bf16_t* hfrag = nullptr;              // fused_qa: norm1 of the patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
-    hipGraphExec_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
-    GraphKey gkey[5]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] / [4]: [0] / [1] of the second chain
+    hipGraphExec_t graph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
+    GraphKey gkey[6]{};                                      // [2] early-exit step (dd_sample_early_exit), [3] / [4] / [5]: [0] / [1] / [2] of the second chain
     WsOffsets wsoff{}, wsoff2{};                             // layout of the main workspace (max_batch) and of the second chain's (half of it)
     char* wsarena2 = nullptr;                                // the second chain's workspace (allocated by the first chained dd_sample)
     WsPtrs ws2;
-    float* ee_ws = nullptr;                                  // dd_sample_early_exit scratch: eps | model_output | cls | outs
+    float* ee_ws = nullptr;                                  // dd_sample_early_exit scratch: eps | model_output | cls | outs (two chains: one such block per chain, half the batch each)
+    float* ee_sums = nullptr;                                // ... and the chains' per-step sums of the predicted errors [2][1000][depth]
     size_t ee_ws_elems = 0;
     // in-context timing (dd_profile_steps): event pairs recorded around each launch of kind ctx->prof_kind when enabled
     bool time_fc1 = false;
@@ -507,7 +509,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             // stream, beside this block's norm1 / qkv / attention launches (which only read x); joined before the first launch that
             // writes x (attn.proj).  Out-blocks start with skip_linear, which overwrites x: their heads stay in line.
             const HeadW& hd = m->heads[bi];
-            ee_side = !is_out && c->side && s != c->side;
+            ee_side = !is_out && c->side && s != c->side && !c->ee_inline;
             hipStream_t hs = ee_side ? c->side : s;
             if (ee_side) {
                 DD_HIP(c, hipEventRecord(c->ev_ee_fork, s));
@@ -683,6 +685,10 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     h_ready = true; qkv_done = true;
                 }
                 mlp_fused_plan(B, m->N, m->extras, L, m->hidden, fa);
+                // The LAST block's projection / MLP of the extra-token rows feed nothing: the output head decodes the patch rows only
+                // (models/uvit.py:377-380 slices the extras off), and those rows' K / V went into this block's attention before.  No
+                // proj_rows / hidden-split workgroups / reduce launch for them.
+                if (bi + 1 == nb && m->fused_proj) { fa.n_extra = 0; fa.tiles_left = 0; }
                 if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
                 if (int rc = mark(DD_PROF_BLOCK_TAIL)) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
@@ -837,8 +843,8 @@ int stage_inputs(dd_ctx* c, const float* x_dev, const int64_t* y_dev, int B, siz
 // large batches (ImageNet-64, B = 256) with the persistent GEMM grids of both chains sized for HALF the CUs (chain_gemm_cus): a full-size
 // grid holds every CU's LDS, two of them only queue behind each other (-4.7 %), two half-size ones run side by side (+4.7 %).
 // Development flags force the split on for any even batch, or switch it off.
-bool use_chains(dd_ctx* c, dd_model* m, int B) {
-    if ((c->dev_flags & DD_DEV_NO_CHAINS) || (B & 1) || B < 2 || m->ee_type >= 0) return false;
+bool use_chains(dd_ctx* c, dd_model* m, int B, bool early_exit_loop = false) {
+    if ((c->dev_flags & DD_DEV_NO_CHAINS) || (B & 1) || B < 2 || ((m->ee_type >= 0) != early_exit_loop)) return false;
     return B >= 32 || (c->dev_flags & DD_DEV_FORCE_CHAINS);
 }
 int chain_gemm_cus(dd_ctx* c, dd_model* m, int B) {
@@ -1307,6 +1313,7 @@ void dd_model_destroy(dd_model* m) {
     for (auto g : m->graph) if (g) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : m->fc1_events) (void)hipEventDestroy(e);
     if (m->ee_ws) (void)hipFree(m->ee_ws);
+    if (m->ee_sums) (void)hipFree(m->ee_sums);
     if (m->warena) (void)hipFree(m->warena);
     if (m->wsarena) (void)hipFree(m->wsarena);
     if (m->wsarena2) (void)hipFree(m->wsarena2);
@@ -1606,11 +1613,13 @@ int dd_sample_affine(dd_ctx* c, const dd_affine_sample_args* a, void* stream) {
 
 // One early-exit sampling step on the device (reference eesampler.py:56-81): EarlyExitUViT.forward with every head and
 // probe -> per-sample exit selection -> DDPM update with the selected output; rows t of the two log tables are written.
-static int enqueue_ee_step(dd_ctx* c, dd_model* m, float* x, const int64_t* y, float thr, float* err_tab, int32_t* idx_tab,
-                           int noise_mode, int B, hipStream_t s) {
+// ws: the chain's scratch block (eps | model_output | cls | outs for B images); b0 / B_all: the chain's first image within the whole batch and
+// the whole batch (idx_tab rows are B_all wide); sums: err_tab is the chain's table of per-layer SUMS (launch_ee_mean_combine joins the chains)
+static int enqueue_ee_step(dd_ctx* c, dd_model* m, float* ws, float* x, const int64_t* y, float thr, float* err_tab, int32_t* idx_tab,
+                           int noise_mode, int B, hipStream_t s, int b0 = 0, int B_all = 0, bool sums = false) {
     const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
     const int depth = m->cfg.depth;
-    float* eps = m->ee_ws;
+    float* eps = ws;
     float* mo = eps + (size_t)B * chw;
     float* cls = mo + (size_t)B * chw;
     float* outs = cls + (size_t)depth * B;
@@ -1620,8 +1629,8 @@ static int enqueue_ee_step(dd_ctx* c, dd_model* m, float* x, const int64_t* y, f
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps, nullptr, c->st, c->coef,
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
     DD_HIP(c, launch_final(fa, s));
-    DD_HIP(c, launch_ee_select(outs, eps, cls, thr, depth, B, chw, mo, idx_tab, err_tab, c->st, s));
-    DD_HIP(c, launch_ddpm_step_state(x, mo, c->st, c->coef, B, m->cfg.in_chans, m->cfg.img_size, noise_mode, 1, s));
+    DD_HIP(c, launch_ee_select(outs, eps, cls, thr, depth, B, chw, mo, idx_tab, err_tab, c->st, s, B_all > 0 ? B_all : B, b0, sums));
+    DD_HIP(c, launch_ddpm_step_state(x, mo, c->st, c->coef, B, m->cfg.in_chans, m->cfg.img_size, noise_mode, 1, s, b0));
     return DD_OK;
 }
 
@@ -1646,22 +1655,64 @@ int dd_sample_early_exit(dd_ctx* c, const dd_ee_sample_args* a, void* stream) {
     }
     float* x_run = a->x_dev;
     const int64_t* y_run = a->y_dev;
+    // Two half-batch chains, as dd_sample: the samples are independent (every exit decision is per sample); the one quantity over the whole
+    // batch -- the logged per-layer mean of the predicted errors, eesampler.py:70 -- becomes per-chain sums that one small launch joins
+    // behind the loop, (chain 0 + chain 1) / B.  Heads and probes stay on each chain's own stream.
+    const bool chained = a->use_graph && use_chains(c, m, a->B, true);
+    const int B0 = chained ? a->B / 2 : a->B, B1 = a->B - B0;
+    c->last_chains = chained ? 2 : 1;
+    float* ws1 = m->ee_ws + (size_t)B0 * ((2 + m->cfg.depth) * chw + m->cfg.depth);     // (the block's size is linear in the batch: two halves fit)
+    float *sum0 = nullptr, *sum1 = nullptr;
+    if (chained && a->err_dev) {
+        if (!m->ee_sums) DD_HIP(c, hipMalloc((void**)&m->ee_sums, (size_t)2 * 1000 * m->cfg.depth * sizeof(float)));
+        sum0 = m->ee_sums; sum1 = m->ee_sums + (size_t)1000 * m->cfg.depth;
+    }
+    struct InlineGuard { dd_ctx* c; bool saved; ~InlineGuard() { c->ee_inline = saved; } } inline_guard{c, c->ee_inline};
+    c->ee_inline = chained;
     if (a->use_graph) {
         if ((rc = stage_inputs(c, a->x_dev, a->y_dev, a->B, (size_t)a->B * chw, s, &x_run, &y_run))) return rc;
-        GraphKey key{x_run, y_run, a->B, a->noise_mode, 0, c->num_cus, nullptr};
-        key.aux0 = a->err_dev; key.aux1 = a->idx_dev; key.thr = a->threshold;
-        auto step = [&](dd_model* mm) { return enqueue_ee_step(c, mm, x_run, y_run, a->threshold, a->err_dev, a->idx_dev, a->noise_mode, a->B, s); };
+        GraphKey key{x_run, y_run, B0, a->noise_mode, 0, c->num_cus, nullptr};
+        key.aux0 = chained ? (const void*)sum0 : (const void*)a->err_dev; key.aux1 = a->idx_dev; key.thr = a->threshold; key.b0 = chained ? -1 : 0;   // (-1: chain 0 of two -- not the whole batch's graph)
+        auto step = [&](dd_model* mm) {
+            return enqueue_ee_step(c, mm, mm->ee_ws, x_run, y_run, a->threshold, chained ? sum0 : a->err_dev, a->idx_dev, a->noise_mode, B0, s, 0, a->B, chained);
+        };
         if ((rc = get_graph(c, m, 2, key, s, step))) return rc;
+        if (chained) {
+            float* x1 = x_run + (size_t)B0 * chw;
+            const int64_t* y1 = y_run ? y_run + B0 : nullptr;
+            GraphKey key1{x1, y1, B1, a->noise_mode, 0, c->num_cus, nullptr};
+            key1.aux0 = sum1; key1.aux1 = a->idx_dev; key1.thr = a->threshold; key1.b0 = B0;
+            auto step1 = [&](dd_model* mm) {
+                swap_chain(mm); std::swap(c->st, c->st2);
+                const int r = enqueue_ee_step(c, mm, ws1, x1, y1, a->threshold, sum1, a->idx_dev, a->noise_mode, B1, s, B0, a->B, true);
+                swap_chain(mm); std::swap(c->st, c->st2);
+                return r;
+            };
+            if ((rc = ensure_chain_ws(c, m, s)) || (rc = get_graph(c, m, 5, key1, s, step1))) return rc;
+        }
     }
     DD_HIP(c, launch_set_state(c->st, a->t_start, (unsigned long long)a->seed, s));
+    if (chained) {
+        DD_HIP(c, launch_set_state(c->st2, a->t_start, (unsigned long long)a->seed, s));
+        DD_HIP(c, hipEventRecord(c->ev_fork, s));
+        DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
+    SideJoin side_join{c, chained};
     DD_HIP(c, hipEventRecord(c->ev[0], s));
     for (int t = a->t_start; t >= a->t_end; --t) {
         if (a->use_graph) {
             DD_HIP(c, hipGraphLaunch(m->graph[2], s));
+            if (chained) DD_HIP(c, hipGraphLaunch(m->graph[5], c->side));
         } else {
-            rc = enqueue_ee_step(c, m, x_run, y_run, a->threshold, a->err_dev, a->idx_dev, a->noise_mode, a->B, s);
+            rc = enqueue_ee_step(c, m, m->ee_ws, x_run, y_run, a->threshold, a->err_dev, a->idx_dev, a->noise_mode, a->B, s);
             if (rc) return rc;
         }
+    }
+    if (chained) {
+        DD_HIP(c, hipEventRecord(c->ev_join, c->side));
+        DD_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        side_join.armed = false;
+        if (a->err_dev) DD_HIP(c, launch_ee_mean_combine(sum0, sum1, a->err_dev, m->cfg.depth, a->t_end, a->t_start, a->B, s));
     }
     DD_HIP(c, hipEventRecord(c->ev[1], s));
     DD_HIP(c, hipEventRecord(c->ev[2], s));

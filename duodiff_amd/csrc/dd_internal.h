@@ -303,10 +303,14 @@ hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out,
 hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, float* srow, int B, int L, int D,
                            const StepState* st, int t_mul, int add, hipStream_t s);
 // st != null: idx / err_mean are [1000, B] / [1000, depth] tables and row st->t_final is written
+// a half-batch chain (dd_sample_early_exit): B = the chain's images, idx rows are idx_stride = the whole batch wide and the chain writes from
+// column idx_col0 on; sums: err_mean receives the plain per-layer SUM over the chain's images (launch_ee_mean_combine joins the chains)
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
-                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s);
+                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s, int idx_stride = 0, int idx_col0 = 0, bool sums = false);
+hipError_t launch_ee_mean_combine(const float* s0, const float* s1, float* err, int depth, int t_lo, int t_hi, int B, hipStream_t s);
+// b0: index of the launch's first image within the whole batch (only the Philox pixel ids depend on it)
 hipError_t launch_ddpm_step_state(float* x, const float* eps, StepState* st, const StepCoef* coef, int B, int C, int S,
-                                  int noise_mode, int advance, hipStream_t s);
+                                  int noise_mode, int advance, hipStream_t s, int b0 = 0);
 hipError_t launch_set_state(StepState* st, int t, unsigned long long seed, hipStream_t s);
 hipError_t launch_set_state_table(StepState* st, const AffineRow* atab, unsigned long long seed, hipStream_t s);   // step index 0
 hipError_t launch_set_state_float(StepState* st, float t, hipStream_t s);

@@ -692,7 +692,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
 // to the next step.  x [B, C, S, S] in place; one thread per pixel.
 __global__ void __launch_bounds__(256) ddpm_step_state_kernel(float* __restrict__ x, const float* __restrict__ eps, StepState* st,
                                                               const StepCoef* __restrict__ coef, int B, int C, int S,
-                                                              int noise_mode, int advance) {
+                                                              int noise_mode, int advance, long long pix0) {
 #pragma clang fp contract(off)
     const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long hw = (long long)S * S;
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) ddpm_step_state_kernel(float* __restrict_
     if (pix >= (long long)B * hw) return;
     const StepCoef cf = coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
     f32x4 zn = {0.f, 0.f, 0.f, 0.f};
-    if (t > 0 && noise_mode == 2) zn = philox_normal4(st->seed, (unsigned long long)pix, t);
+    if (t > 0 && noise_mode == 2) zn = philox_normal4(st->seed, (unsigned long long)(pix + pix0), t);     // pix0: a half-batch chain's first pixel within the whole batch
     const long long b = pix / hw, p = pix - b * hw;
     for (int c = 0; c < C; ++c) {
         const long long e = (b * C + c) * hw + p;
@@ -863,10 +863,11 @@ __global__ void __launch_bounds__(256) ee_attn_probe_kernel(const float* __restr
 // list (torch.argmax of an all-False column is 0); model_output[b] = (outputs ++ [eps])[idx[b]][b].
 __global__ void ee_select_kernel(const float* __restrict__ outs, const float* __restrict__ eps, const float* __restrict__ cls,
                                  float thr, int depth, int B, long long chw, float* __restrict__ mo, int* __restrict__ idx_out,
-                                 const StepState* __restrict__ st) {
+                                 const StepState* __restrict__ st, int idx_stride, int idx_col0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * chw) return;
-    if (st && idx_out) idx_out += (long long)st->t_final * B;     // row t of indices_by_timestep (eesampler.py:71)
+    // row t of indices_by_timestep (eesampler.py:71); a half-batch chain writes its columns [idx_col0, idx_col0 + B) of the whole batch's row
+    if (st && idx_out) idx_out += (long long)st->t_final * idx_stride + idx_col0;
     const int b = (int)(i / chw);
     int idx = -1;
     for (int k = 0; k < depth && idx < 0; ++k)
@@ -877,15 +878,24 @@ __global__ void ee_select_kernel(const float* __restrict__ outs, const float* __
 }
 
 // eesampler.py:70: per-layer mean over the batch of the predicted errors (logging)
+// (scale = 1 / B: the mean; scale = 1: the plain sum -- a half-batch chain's share, ee_mean_combine_kernel divides)
 __global__ void __launch_bounds__(64) ee_batch_mean_kernel(const float* __restrict__ cls, float* __restrict__ err, int B,
-                                                           const StepState* __restrict__ st) {
+                                                           const StepState* __restrict__ st, float scale) {
     const int k = blockIdx.x, lane = threadIdx.x;
     if (st) err += (long long)st->t_final * gridDim.x;            // row t of error_prediction_by_timestep (eesampler.py:70)
     float a = 0.f;
     for (int b = lane; b < B; b += 64) a += cls[(long long)k * B + b];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) err[k] = a / (float)B;
+    if (lane == 0) err[k] = scale == 1.0f ? a : a / (float)B;
+}
+
+// rows [t_lo, t_hi] of error_prediction_by_timestep from the two chains' per-step sums, in a fixed order: (chain 0 + chain 1) / B
+__global__ void ee_mean_combine_kernel(const float* __restrict__ s0, const float* __restrict__ s1, float* __restrict__ err, int depth, int t_lo, int t_hi, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = (t_hi - t_lo + 1) * depth;
+    if (i >= n) return;
+    const long long e = (long long)t_lo * depth + i;
+    err[e] = (s0[e] + s1[e]) / (float)B;
 }
 
 }  // namespace
@@ -1158,17 +1168,23 @@ hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out,
     return hipGetLastError();
 }
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
-                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s) {
+                            float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s, int idx_stride, int idx_col0, bool sums) {
     const long long n = (long long)B * chw;
-    hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx, st);
-    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B, st);
+    hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx, st,
+                       idx_stride > 0 ? idx_stride : B, idx_col0);
+    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B, st, sums ? 1.0f : 0.0f);
+    return hipGetLastError();
+}
+hipError_t launch_ee_mean_combine(const float* s0, const float* s1, float* err, int depth, int t_lo, int t_hi, int B, hipStream_t s) {
+    const int n = (t_hi - t_lo + 1) * depth;
+    hipLaunchKernelGGL(ee_mean_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, s0, s1, err, depth, t_lo, t_hi, B);
     return hipGetLastError();
 }
 hipError_t launch_ddpm_step_state(float* x, const float* eps, StepState* st, const StepCoef* coef, int B, int C, int S,
-                                  int noise_mode, int advance, hipStream_t s) {
+                                  int noise_mode, int advance, hipStream_t s, int b0) {
     const long long npix = (long long)B * S * S;
     hipLaunchKernelGGL(ddpm_step_state_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, eps, st, coef, B, C, S,
-                       noise_mode, advance);
+                       noise_mode, advance, (long long)b0 * S * S);
     return hipGetLastError();
 }
 

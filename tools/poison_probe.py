@@ -42,7 +42,53 @@ def one(name, cfg, B, prec, flags=0):
     print(f"{name:44s} B={B:3d} {prec} flags={flags:5d}: {'ok' if same else 'DIFFERS'}  (NaN fraction after poison {nanf:.3f}, clean finite {bool(torch.isfinite(outs[0]).all())})", flush=True)
 
 
+def loop(name, cfg_s, cfg_f, B, prec, flags, steps=8, tsw=3, use_graph=True):
+    """the sampling loop (dd_sample) on a fresh model pair vs after poisoning both models' workspaces"""
+    from duodiff_amd.engine import Context, sample_loop
+    outs = []
+    for poison in (False, True):
+        ctx = Context.get()
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+        ms = []
+        for cfg, seed in ((cfg_s, 131), (cfg_f, 132)):
+            mp = ModelParams.from_dict(cfg)
+            ms.append(UViT(**mp.as_dict(), precision=prec, max_batch=B).load_state_dict(synthetic_state_dict(mp, seed)).to("cuda"))
+        es, ef = ms[0].engine_model(B), ms[1].engine_model(B)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        x = torch.randn(B, mp.in_chans, mp.img_size, mp.img_size, generator=torch.Generator().manual_seed(14)).cuda()
+        y = torch.randint(0, mp.num_classes, (B,), generator=torch.Generator().manual_seed(15)).cuda() if mp.num_classes > 0 else None
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            if poison:
+                for e in (es, ef):
+                    ctx.check(ctx.lib.dd_dev_poison_workspaces(ctx.handle, e.handle, stream.cuda_stream))
+            sample_loop(ctx, es, ef, x, t_switch=tsw, t_start=999, t_end=1000 - steps, y=y, seed=19, noise="philox", use_graph=use_graph, stream=stream)
+            stream.synchronize()
+        outs.append(x.cpu())
+        ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+        del es, ef, ms
+    bad = (outs[0] != outs[1]).flatten(1).any(1).nonzero().flatten().tolist()
+    print(f"loop {name:40s} B={B:3d} {prec} flags={flags:5d} steps={steps} tsw={tsw} graph={int(use_graph)}: {'ok' if not bad else 'DIFFERS: images ' + str(bad[:8])}"
+          f"  (NaN fraction {float(torch.isnan(outs[1]).float().mean()):.3f})", flush=True)
+
+
 def main():
+    for prec in ("bf16", "fp32"):
+        one("tiny depth 1", dict(TINY, depth=1), 3, prec)
+        one("tiny depth 1, max_batch 6 run at 3", dict(TINY, depth=1), 3, prec)
+    t1, t3 = dict(TINY, depth=1), dict(TINY, depth=3)
+    loop("tiny pair single chain", t1, t3, 6, "bf16", L.DD_DEV_NO_CHAINS)
+    loop("tiny pair single chain, eager", t1, t3, 6, "bf16", L.DD_DEV_NO_CHAINS, use_graph=False)
+    loop("tiny pair single chain, no switch", t3, t3, 6, "bf16", L.DD_DEV_NO_CHAINS, tsw=0)
+    loop("tiny pair single chain, 1 step", t3, t3, 6, "bf16", L.DD_DEV_NO_CHAINS, steps=1, tsw=0)
+    loop("tiny pair single chain, 2 steps", t3, t3, 6, "bf16", L.DD_DEV_NO_CHAINS, steps=2, tsw=0)
+    loop("tiny pair forced chains", t1, t3, 6, "bf16", L.DD_DEV_FORCE_CHAINS)
+    loop("tiny pair forced chains, no switch", t3, t3, 6, "bf16", L.DD_DEV_FORCE_CHAINS, tsw=0)
+    loop("tiny pair fp32 single", t1, t3, 6, "fp32", L.DD_DEV_NO_CHAINS)
+    loop("celeba pair default", load_config(REPO / "configs" / "uvit_celeba_3.yaml"), load_config(REPO / "configs" / "uvit_celeba.yaml"), 64, "bf16", 0, steps=4, tsw=2)
+    return
+
     w = lambda D, nc, depth=3: dict(img_size=32, patch_size=2, in_chans=3, embed_dim=D, depth=depth, num_heads=D // 64, mlp_ratio=4, qkv_bias=False,
                                     mlp_time_embed=False, num_classes=nc, normalize_timesteps=True)
     for prec in ("bf16", "fp32"):
