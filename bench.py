@@ -38,13 +38,13 @@ from duodiff_amd.weights import synthetic_state_dict  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-def _latest_profile_dir():
-    """The newest profiles/rNN that holds the headline workload's rocprofv3 kernel table (tools/collect_profiles.sh writes one per round)."""
-    ds = sorted((d for d in (REPO / "profiles").glob("r[0-9][0-9]") if (d / "kernel_stats.csv").exists()), reverse=True)
-    return ds[0] if ds else REPO / "profiles" / "r05"
+def profile_file(name):
+    """profiles/rNN/<name> of the newest round that holds it (tools/collect_profiles.sh writes one directory per round), or None."""
+    for d in sorted((REPO / "profiles").glob("r[0-9][0-9]"), reverse=True):
+        if (d / name).exists():
+            return d / name
+    return None
 
-
-PROFILE_DIR = _latest_profile_dir()   # committed rocprofv3 summaries: kernel tables (which kernel dominates) and --pmc counters keyed by build id
 
 # kernel families the library can bracket with event pairs (include/duodiff.h DD_PROF_*): name fragment in rocprofv3's table -> kind
 FAMILIES = (("mlp_fused_kernel", "block_tail"), ("qkv_attention_kernel", "qkv_attention"), ("rowlin768_kernel", "rowlin"),
@@ -180,10 +180,10 @@ def committed_pmc(build_id, workload, kernel_substr):
     Returns {"traffic": HBM bytes per launch, "mfma_busy": MFMA-busy clocks / clocks of the launch, "sclk_mhz": clock held under it}."""
     sfx = "" if workload == "celeba" else f"_{workload}"
     try:
-        pmc = json.load(open(PROFILE_DIR / f"pmc_traffic{sfx}.json"))
-        sq = json.load(open(PROFILE_DIR / f"pmc_sq{sfx}.json"))
+        pmc = json.load(open(profile_file(f"pmc_traffic{sfx}.json")))
+        sq = json.load(open(profile_file(f"pmc_sq{sfx}.json")))
     except Exception as e:
-        return {}, f"no committed PMC profile of {workload} under {PROFILE_DIR.relative_to(REPO)} ({type(e).__name__})"
+        return {}, f"no committed PMC profile of {workload} under profiles/ ({type(e).__name__})"
     have = pmc.get("_build_id"), sq.get("_build_id")
     if have[0] != build_id or have[1] != build_id:
         return {}, (f"committed PMC profile is of another build ({have[0]} / {have[1]}, running {build_id}): counters not quoted")
@@ -207,7 +207,7 @@ def kernel_shares(workload):
     import csv
     sfx = "" if workload == "celeba" else f"_{workload}"
     try:
-        rows = list(csv.DictReader(open(PROFILE_DIR / f"kernel_stats{sfx}.csv")))
+        rows = list(csv.DictReader(open(profile_file(f"kernel_stats{sfx}.csv"))))
     except Exception:
         return []
     total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
@@ -448,6 +448,9 @@ def main():
         # HBM bytes / MFMA-busy fraction of that kernel: quoted from the COMMITTED rocprofv3 --pmc profile only when that profile
         # was collected on the build that is running (rocprofv3 cannot run inside this process); null + reason otherwise
         pm, why_not = committed_pmc(build_id, a.workload, pmc_kernel)
+        sfx_ = "" if a.workload == "celeba" else f"_{a.workload}"
+        rel = lambda f: str(f.relative_to(REPO)) if f else "profiles/"
+        pmc_rel, stats_rel = rel(profile_file(f"pmc_traffic{sfx_}.json")), rel(profile_file(f"kernel_stats{sfx_}.csv"))
         traffic, mfma_busy, sclk = pm.get("traffic"), pm.get("mfma_busy"), pm.get("sclk_mhz")
         log(f"dominant kernel: {ms * 1e3:.1f} us = {ach:.0f} TFLOP/s")
         out = {
@@ -472,19 +475,18 @@ def main():
                        "library_build_id": build_id},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": (f"bytes/launch from the committed rocprofv3 --pmc profile {PROFILE_DIR.relative_to(REPO)}/pmc_traffic.json, "
+                         "traffic_source": (f"bytes/launch from the committed rocprofv3 --pmc profile {pmc_rel}, "
                                             f"collected on this build ({build_id}); not measured in this run") if traffic else why_not,
                          "algorithmic_bytes": alg_bytes,
                          "kernel": kname,
-                         "kernel_chosen_from": (f"largest total time in {PROFILE_DIR.relative_to(REPO)}/kernel_stats{'' if a.workload == 'celeba' else '_' + a.workload}.csv"
-                                                if shares else "design default (no committed kernel table for this workload / precision)"),
+                         "kernel_chosen_from": (f"largest total time in {stats_rel}" if shares else "design default (no committed kernel table for this workload / precision)"),
                          "kernels": top,
                          "ms_per_launch": ms, "ms_per_launch_source": "measured live (hipEvents on the launch stream)",
                          "launches_timed": n_launch, "flops_per_launch": fl,
                          "end_to_end_tflops_per_gpu": e2e_tflops, "end_to_end_frac": e2e_tflops / BF16_MFMA_PEAK_TFLOPS,
                          "hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBps": HBM_PEAK_GBS,
                          "mfma_busy_frac_pmc": mfma_busy,
-                         "mfma_busy_source": (f"SQ_VALU_MFMA_BUSY_CYCLES per SIMD / (GRBM_GUI_ACTIVE / 8) of the launch, committed profile {PROFILE_DIR.relative_to(REPO)}/pmc_sq*.json "
+                         "mfma_busy_source": (f"SQ_VALU_MFMA_BUSY_CYCLES per SIMD / (GRBM_GUI_ACTIVE / 8) of the launch, committed profile {pmc_rel} (pmc_sq*.json) "
                                               f"of this build; not measured in this run") if mfma_busy else why_not,
                          "sclk_mhz_under_load": sclk,
                          "sclk_source": ("GRBM_GUI_ACTIVE / 8 / launch duration of the same committed profile (profiled passes clock 2-5 % below un-profiled ones)") if sclk else why_not,

@@ -689,7 +689,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 // (models/uvit.py:377-380 slices the extras off), and those rows' K / V went into this block's attention before.  No
                 // proj_rows / hidden-split workgroups / reduce launch for them.
                 if (bi + 1 == nb && m->fused_proj) { fa.n_extra = 0; fa.tiles_left = 0; }
-                if (m->fused_proj) DD_HIP(c, launch_proj_rows(fa, D, s));   // the extra-token rows (not in the main tiles)
+                if (m->fused_proj) fa.reduce_set = 1;   // the extra-token rows' projection runs in their hidden-split workgroups: the first group's slab carries x + proj(ao) + b
                 if (int rc = mark(DD_PROF_BLOCK_TAIL)) return rc;
                 DD_HIP(c, launch_mlp_fused(fa, D, s));
                 if (int rc = mark(DD_PROF_BLOCK_TAIL)) return rc;              // (the event pair brackets the fused kernel alone)
@@ -1916,14 +1916,14 @@ int dd_dev_mlp(dd_ctx* c, int M, int D, int hidden, int extras, const float* x_h
     }
     a.X = (const bf16_t*)dX; a.ldx = D; a.wimg = (const char*)dI; a.b1p = (const float*)dB1; a.b2 = (const float*)dB2;
     a.xres = (float*)dXr; a.out = out_host ? (bf16_t*)dO : nullptr; a.ldo = D; a.partial = (float*)dP;
-    if (proj) {   // as run_backbone does it: patch rows inside the launch, extra-token rows by the small kernel in front
+    if (proj) {   // as run_backbone does it: patch rows in the main tiles, extra-token rows in their hidden-split workgroups
         std::vector<unsigned short> ah(Mp * D, 0);
         for (size_t i = 0; i < (size_t)M * D; ++i) ah[i] = host_f2bf(ao_host[i]);
         DD_TRY(hipMalloc(&dAo, ah.size() * 2)); DD_TRY(hipMalloc(&dBp, D * 4));
         DD_TRY(hipMemcpy(dAo, ah.data(), ah.size() * 2, hipMemcpyHostToDevice));
         DD_TRY(hipMemcpy(dBp, bproj, D * 4, hipMemcpyHostToDevice));
         a.ao = (const bf16_t*)dAo; a.bproj = (const float*)dBp; a.nproj = D / 32;
-        DD_TRY(launch_proj_rows(a, D, s));
+        a.reduce_set = 1;        // (the extra-token rows' projection runs in their hidden-split workgroups, run_backbone)
     }
     MlpFusedArgs ar = a;       // (what the reduce launch gets: see run_backbone)
     if (skp) {

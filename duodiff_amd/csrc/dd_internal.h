@@ -140,7 +140,8 @@ struct MlpFusedArgs {
     int n_main, n_extra;   // B * tok_n patch rows (main tiles), B * tok_e extra rows (hidden-split tiles)
     int tiles_main, tiles_left, groups, cpg;
     int prows;             // rows per hidden-split tile (32, 64 or 128: whole waves)
-    int reduce_set = 0;    // launch_mlp_reduce: x = b2 + slabs instead of x += (the extra-token rows of a row-resident skip_linear)
+    int reduce_set = 0;    // launch_mlp_reduce: x = b2 + slabs instead of x += (the extra-token rows of a row-resident skip_linear; of a block tail with the
+                           // projection in front: the first hidden group's slab carries x + proj(ao) + b)
 };
 bool mlp_fused_supported(int D, int hidden);
 size_t mlp_fused_image_bytes(int D, int hidden, bool with_proj, bool with_skip, bool with_qkv);
@@ -155,7 +156,6 @@ size_t mlp_fused_partial_bytes(int max_batch, int extras, int D, int hidden);
 void mlp_fused_plan(int B, int n_patches, int extras, int seq_len, int hidden, MlpFusedArgs& a);
 void mlp_fused_pack(int D, int hidden, const float* w1, const float* b1, const float* w2, bool kperm,
                     unsigned short (*to_bf16)(float), unsigned short* img, float* b1p);
-hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t launch_mlp_fused(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t launch_mlp_reduce(const MlpFusedArgs& a, int D, hipStream_t s);
 hipError_t init_mlp_fused_kernels();

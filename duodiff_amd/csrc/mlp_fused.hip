@@ -270,9 +270,9 @@ struct MlpCfg {
 template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false, bool QKV = false>
 __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
-    static_assert(!PROJ || (LNIN && !PARTIAL && C::NT % 4 == 0), "proj fusion: main tiles of the LayerNorm-in kernel, D % 128 == 0");
-    static_assert(!SKIP || PROJ, "skip fusion rides on the proj-fused main tiles");
-    static_assert(!QKV || PROJ, "qkv fusion rides on the proj-fused main tiles");
+    static_assert(!PROJ || (LNIN && C::NT % 4 == 0), "proj fusion: the LayerNorm-in kernel, D % 128 == 0");
+    static_assert(!SKIP || (PROJ && !PARTIAL), "skip fusion rides on the proj-fused main tiles");
+    static_assert(!QKV || (PROJ && !PARTIAL), "qkv fusion rides on the proj-fused main tiles");
     float* b1s = reinterpret_cast<float*>(smem + C::RING);           // [hidden + 32], in accumulator-register order per chunk
     float* vecs = b1s + (a.nchunks + 1) * 32;                        // 7 x [D]: ln_in gamma, beta | ln_out gamma, beta | b2 | bproj | bskip
     // weight stream: [nproj blocks of Wproj][W1(0) W2(0) W1(1) W2(1) ...]; stream position p lives in ring slot p & 3
@@ -320,9 +320,10 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
     // prologue: the first three blocks of the stream (W1(c0), W2(c0), W1(c0+1); with PROJ the first three Wproj blocks) in
     // flight while the X fragments and the bias table are fetched.  c0 is even (mlp_fused_plan), so block b always lives
     // in ring slot b & 3: W1(c) in slot 0 / 2, W2(c) in slot 1 / 3.
-    dma_block(2 * c0, 0);
-    dma_block(2 * c0 + 1, 1);
-    dma_block(2 * c0 + 2, 2);
+    const int pb0 = PROJ ? 0 : 2 * c0;     // (PROJ: the projection's blocks lead the stream whatever hidden range follows)
+    dma_block(pb0, 0);
+    dma_block(pb0 + 1, 1);
+    dma_block(pb0 + 2, 2);
     if constexpr (!PROJ) {   // slot 3 stands in for "W2 of chunk c0-1": zeros, so that the first iteration's GEMM2 adds nothing
         // (PROJ: the last Wproj block sits there -- finite, and multiplied by the all-zero activations of "chunk -1")
         f32x4* z = reinterpret_cast<f32x4*>(smem + 3 * C::BLK);
@@ -385,7 +386,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
         float cshift = 0.f;      // shift of the one-pass statistics: the lane's first element (ln_stats_shifted)
         // LA tiles of loads in flight, no more: sched_barrier keeps hipcc from hoisting all 64 loads (256 registers)
         // above the arithmetic (that version spilled); statistics in one pass on register quads (packed fp32 math)
-        constexpr int LA = C::NT < 4 ? C::NT : (PARTIAL && C::NT >= 8) ? 8 : 4;   // hidden-split tiles: nothing else is live yet, and the workgroup is pure latency
+        constexpr int LA = C::NT < 4 ? C::NT : (PARTIAL && !PROJ && C::NT >= 8) ? 8 : 4;   // hidden-split tiles without the projection: nothing else is live yet, and the workgroup is pure latency
         f32x4 xq[LA][4];
         const float* lbp = vecs + 5 * D + 4 * h;     // (PROJ) attn.proj bias
         if constexpr (PROJ) {
@@ -446,8 +447,9 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                     if constexpr (f == C::F / 2) {
                         wait_vmcnt<C::FPW>();
                         __builtin_amdgcn_s_barrier();
-                        // stream position t + 3: Wproj block, or (t + 3 >= NT) block t + 3 - NT of the MLP part
-                        const char* src = uniform_ptr(a.wimg + (size_t)(t + 3) * C::BLK);
+                        // stream position t + 3: Wproj block, or (t + 3 >= NT) block 2 c0 + t + 3 - NT of the MLP part (c0 = 0 for main tiles;
+                        // a hidden-split workgroup continues with ITS hidden range: c0 is even, so the ring slot parity holds)
+                        const char* src = uniform_ptr(a.wimg + (size_t)(t + 3) * C::BLK + (t + 3 >= C::NT ? (size_t)(2 * c0) * C::BLK : (size_t)0));
                         char* dst = smem + ((t + 3) & 3) * C::BLK + (wave * C::FPW) * 1024;
                         [&]<int... J>(std::integer_sequence<int, J...>) { (glds16u_j<J>(src, dma_voff, dst), ...); }(std::make_integer_sequence<int, C::FPW>{});
                     }
@@ -505,9 +507,17 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                 }
                 xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
             }
-            if constexpr (PARTIAL) {                 // hidden-split tiles accumulate a partial sum: the row only passed through
+            if constexpr (PARTIAL && !PROJ) {        // hidden-split tiles accumulate a partial sum: the row only passed through
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Y[t][e] = 0.f;
+                acc_pin(Y[t]);
+            } else if constexpr (PARTIAL) {
+                // ... with the projection in front, every group of a tile has computed x1 = x + proj(ao) + b for its rows (the LayerNorm needs all
+                // of it); the FIRST group's slab carries it, so that the reduce launch sets x = b2 + sum of the slabs (MlpFusedArgs::reduce_set)
+                // and no launch writes x1 while another group may still read x.  An exact 1 / 0 factor, not a branch around 256 accumulators.
+                const float keep1 = c0 == 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Y[t][e] = yt[e] * keep1;
                 acc_pin(Y[t]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -982,7 +992,7 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
         const int e = blockIdx.x - a.tiles_main;
         const int lt = e / a.groups, g = e - lt * a.groups;
         const int c0 = g * a.cpg;
-        mlp_body<D, LNIN, true, false>(a, smem, lt, c0, c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks, e);
+        mlp_body<D, LNIN, true, PROJ>(a, smem, lt, c0, c0 + a.cpg < a.nchunks ? c0 + a.cpg : a.nchunks, e);
     }
 }
 
@@ -1045,72 +1055,6 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
         for (int e = 0; e < VPL; ++e)
             a.ln_out[row * D + col + e] = f2bf((xv[e] - mean) * rstd * gv[e] + bv[e]);
     }
-}
-
-// x += ao . Wproj^T + bproj for the extra-token rows (the rows the fused launch's main tiles do not cover; their MLP runs
-// in the hidden-split workgroups, which read the finished x).  Workgroup (t, tile): output columns 32t .. 32t+31 of 128
-// rows, one 32-row group per wave.  The kernel is pure latency (B * extras rows), so every load is issued up front and
-// every one is a full-line access: the attention rows -- a sequence length apart in memory -- go whole rows at a time
-// straight into a wave-private LDS strip (LDS-DMA) and are read back as MFMA B fragments; the Wproj block comes straight
-// from the image's fragment order (one coalesced 16-byte load per lane and k-step).
-template <int D>
-__global__ void __launch_bounds__(256) proj_rows_kernel(const MlpFusedArgs a) {
-    using C = MlpCfg<D>;
-    constexpr int LPR = D / 8;                 // lanes per attention row (16 bytes each)
-    constexpr int RPI = 64 / LPR;              // rows per LDS-DMA instruction (1 KB, lands contiguously)
-    constexpr int NI = 32 / RPI;               // instructions per wave
-    constexpr int IPITCH = 1024 + 32;          // LDS pitch per instruction: 16-byte reads of consecutive rows spread over the banks
-    extern __shared__ __attribute__((aligned(16))) char strip_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    // (launched with ONE wave per workgroup: the waves never talk to each other, and a workgroup's cost is what it pulls through its
-    // CU's L2 port -- 32 rows + the 32 KB weight block instead of 128 rows + the block)
-    const int t = blockIdx.x, idx0 = blockIdx.y * ((int)blockDim.x / 2) + wave * 32;
-    char* strip = strip_lds + wave * (NI * IPITCH);
-    auto row_of = [&](int idx) -> long long {
-        const int q = idx < a.n_extra ? idx : a.n_extra - 1, b = q / a.tok_e;
-        return (long long)b * a.tok_l + (q - b * a.tok_e);
-    };
-#pragma unroll
-    for (int i = 0; i < NI; ++i)               // straight into LDS: no registers held while the rows are in flight
-        glds16(a.ao + row_of(idx0 + i * RPI + lane / LPR) * D + (lane % LPR) * 8, strip + i * IPITCH);
-    __builtin_amdgcn_sched_barrier(0);         // (hipcc puts a vmcnt(0) in front of the first LDS-DMA: nothing may be hoisted above it)
-    const int idx = idx0 + (lane & 31);
-    const bool ok = idx < a.n_extra;
-    const long long row = row_of(idx);
-    const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wimg + (size_t)t * C::BLK) + lane;
-    float* xr = a.xres + row * D + 32 * t + 4 * h;
-    const float* bp = a.bproj + 32 * t + 4 * h;
-    bf16x8 wf[C::F];
-#pragma unroll
-    for (int ks = 0; ks < C::F; ++ks) wf[ks] = wb[ks * 64];
-    f32x4 xq[4], bq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        xq[g] = *reinterpret_cast<const f32x4*>(xr + 8 * g);
-        bq[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
-    }
-    wait_vmcnt<0>();                        // wave-private strip: this wave's DMA has landed (hipcc does not track LDS-DMA writes)
-    bf16x8 af[C::F];
-    const char* my = strip + ((lane & 31) / RPI) * IPITCH + ((lane & 31) % RPI) * (D * 2) + 16 * h;
-#pragma unroll
-    for (int ks = 0; ks < C::F; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(my + 32 * ks);
-    f32x16 acc, acc1;                       // two accumulator chains hide the MFMA's own latency
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[4 * g + e] = xq[g][e] + bq[g][e];      // same order as the main tiles: (x + b) + products
-            acc1[4 * g + e] = 0.f;
-        }
-#pragma unroll
-    for (int ks = 0; ks < C::F; ks += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[ks], acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks + 1], af[ks + 1], acc1, 0, 0, 0);
-    }
-    acc += acc1;
-    if (!ok) return;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(xr + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
 }
 
 // The extra-token rows of a SKIP launch (they left the fused launch through the hidden-split workgroups and the reduce
@@ -1489,8 +1433,6 @@ hipError_t init_mlp_fused_kernels() {
 #undef DD_ATTR
 #define DD_ATTR_P(DV)                                                                                        \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void*)proj_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds); \
-    if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)qkv_rows_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, kProjRowsLds); \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<DV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(DV));
@@ -1499,20 +1441,6 @@ hipError_t init_mlp_fused_kernels() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)skip_rows_ln_kernel<512, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)skip_rows_lds(512));
     return e;
-}
-
-// extra-token rows of the fused projection (a.ao / a.bproj / a.nproj set as for launch_mlp_fused); no-op without extras
-hipError_t launch_proj_rows(const MlpFusedArgs& a, int D, hipStream_t s) {
-    if (a.n_extra <= 0) return hipSuccess;
-    if (a.nproj != D / 32 || !a.ao || !a.bproj) return hipErrorInvalidValue;
-    const dim3 grid(D / 32, (a.n_extra + 31) / 32);
-    switch (D) {
-        case 128: hipLaunchKernelGGL((proj_rows_kernel<128>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
-        case 256: hipLaunchKernelGGL((proj_rows_kernel<256>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
-        case 512: hipLaunchKernelGGL((proj_rows_kernel<512>), grid, dim3(64), kProjRowsLds / 4, s, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 // skip_linear + norm1 of the extra-token rows of a SKIP launch (after launch_mlp_reduce, which stored their y in a.out); no-op without extras

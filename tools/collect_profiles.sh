@@ -12,9 +12,9 @@ mkdir -p $out
 WL="${@:-celeba imagenet64 imagenet256}"
 for W in $WL; do
   sfx=""; [ $W != celeba ] && sfx="_$W"
-  # PMC first: bench.py quotes HBM traffic / MFMA-busy / clock of the dominant kernel from profiles/r04/pmc_*.json when they are of THIS build
+  # PMC first: bench.py quotes HBM traffic / MFMA-busy / clock of the dominant kernel from profiles/rNN/pmc_*.json when they are of THIS build
   bash tools/collect_pmc.sh $W $R/gpurun_out/pmc$sfx > $out/pmc$sfx.log 2>&1
-  for f in pmc_traffic.json pmc_sq.json; do cp gpurun_out/pmc$sfx/$f $out/${f%.json}$sfx.json; cp gpurun_out/pmc$sfx/$f $R/profiles/r04/${f%.json}$sfx.json; done
+  for f in pmc_traffic.json pmc_sq.json; do cp gpurun_out/pmc$sfx/$f $out/${f%.json}$sfx.json; cp gpurun_out/pmc$sfx/$f $R/profiles/${ROUND:-r05}/${f%.json}$sfx.json; done
   cp gpurun_out/pmc$sfx/pmc_traffic_summary.txt $out/pmc_traffic_summary$sfx.txt
   cp gpurun_out/pmc$sfx/pmc_sq_utilisation.txt $out/pmc_sq_utilisation$sfx.txt
   rm -rf $out/kt$sfx && mkdir -p $out/kt$sfx

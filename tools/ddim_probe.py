@@ -36,3 +36,29 @@ for name, flags, noise in (("device loop, two chains", 0, "device"), ("device lo
             best, gpu = dt, (ctx.last_sample_timing() if noise == "device" else None)
     print(f"{name:28s}: wall {best * 1e3:7.2f} ms = {B / best:6.1f} images/s" + (f"; GPU time of the loop {gpu[0]:.2f} ms (first backbone {gpu[1]:.2f}, late {gpu[2]:.2f}), chains {ctx.lib.dd_dev_last_sample_chains(ctx.handle)}" if gpu else ""), flush=True)
 ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
+
+# ---- the early-exit loop the same way (deediff_celeba: 13 blocks + 13 heads + probes), 40 steps
+from duodiff_amd import eesampler  # noqa: E402
+from duodiff_amd.early_exit import EarlyExitUViT  # noqa: E402
+from duodiff_amd.weights import synthetic_ee_state_dict  # noqa: E402
+
+del ms
+cfg = dict(load_config(REPO / "configs" / "deediff_celeba.yaml")["model_params"])
+ctype = cfg.pop("classifier_type")
+mp = ModelParams.from_dict(cfg)
+ee = EarlyExitUViT(UViT(**mp.as_dict(), max_batch=B), ctype).load_state_dict(synthetic_ee_state_dict(mp, 77, ctype)).eval().to("cuda")
+K = 40
+for name, flags in (("early exit, two chains", 0), ("early exit, one chain", L.DD_DEV_NO_CHAINS)):
+    ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, flags))
+    f = lambda: eesampler.get_samples(ee, B, 0, 3, 64, 64, 0.1, mp.depth, noise="device", num_steps=K)
+    f()
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    gpu = ctx.last_sample_timing()
+    print(f"{name:28s}: wall {best / K * 1e3:6.3f} ms per step; GPU time of the loop {gpu[0] / K:.3f} ms per step, chains {ctx.lib.dd_dev_last_sample_chains(ctx.handle)}", flush=True)
+ctx.check(ctx.lib.dd_dev_set_flags(ctx.handle, 0))
