@@ -98,9 +98,9 @@ struct GraphKey {
 struct WsPtrs {
     float* x = nullptr; void *h = nullptr, *ao = nullptr, *qkv = nullptr, *hid = nullptr, *xb = nullptr;
     std::vector<void*> skips;
-    float* dec = nullptr; float* mlp_partial = nullptr; bf16_t* qkv_dump = nullptr; bf16_t* hfrag = nullptr;
+    float* dec = nullptr; float* mlp_partial = nullptr; bf16_t* qkv_dump = nullptr; bf16_t* hfrag = nullptr; float* ytap = nullptr;
 };
-struct WsOffsets { size_t x, h, ao, qkv, hid, xb, dec, part, dump, hf, bytes; std::vector<size_t> sk; bool has_part, has_dump, has_hf; size_t part_bytes = 0; };
+struct WsOffsets { size_t x, h, ao, qkv, hid, xb, dec, part, dump, hf, bytes; std::vector<size_t> sk; bool has_part, has_dump, has_hf; size_t part_bytes = 0; size_t tap = 0; bool has_tap = false; };
 
 struct dd_model {
     dd_ctx* ctx = nullptr;
@@ -127,7 +127,7 @@ struct dd_model {
     std::vector<AttnProbeW> attn_probes;                  // DD_EE_ATTENTION_PROBE: one per layer
     bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
-    bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; not for early-exit models,
+    bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; early-exit models tap y on the way,
                                           //     whose heads read every block's output)
     bool fused_qkv = false;               // ... and the NEXT block's attn.qkv Linear last of all (no qkv bias; not for early-exit models)
     bool splitk = false;                  // GEMM-path models whose N = embed_dim Linears have too few 256 x 256 tiles at max_batch: split-K + reduce_ln launches
@@ -138,6 +138,7 @@ struct dd_model {
                                           // fused_qkv wherever the previous block's fused launch leaves norm1 in h
     bf16_t* qkv_dump = nullptr;           // scratch for the qkv stores of rows past the end of a ragged tile
     bf16_t* hfrag = nullptr;              // fused_qa: norm1 of the patch rows in MFMA fragment order (MlpFusedArgs::ln_out_frag)
+    float* ytap = nullptr;                // early-exit models with fused_skip: the block output y of the launches that run the next skip_linear (MlpFusedArgs::y_tap)
     float* mlp_partial = nullptr;         // partial slabs of hidden-split leftover tiles (mlp_fused_plan)
     size_t mlp_partial_bytes = 0;
     hipGraphExec_t graph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0] DDPM step (dd_sample), [1] table-driven step (dd_sample_affine),
@@ -414,6 +415,7 @@ void bind_ws(const WsOffsets& o, char* arena, WsPtrs& w) {
     w.mlp_partial = o.has_part ? (float*)(arena + o.part) : nullptr;
     w.qkv_dump = o.has_dump ? (bf16_t*)(arena + o.dump) : nullptr;
     w.hfrag = o.has_hf ? (bf16_t*)(arena + o.hf) : nullptr;
+    w.ytap = o.has_tap ? (float*)(arena + o.tap) : nullptr;
 }
 // Layout of one chain's activation workspace for batches up to `batch` (the model's max_batch; half of it, rounded up, for the second
 // half-batch chain of dd_sample, which never runs more).
@@ -437,8 +439,12 @@ WsOffsets ws_layout(const dd_model* m, int batch) {
     const size_t o_part = take(part_bytes);
     const size_t o_dump = take(m->fused_qkv ? 16384 : 0);
     const size_t o_hf = take(m->fused_qa ? (size_t)batch * m->N * D * 2 : 0);
+    const bool has_tap = m->ee_type >= 0 && m->fused_skip;
+    const size_t o_tap = take(has_tap ? Mp * D * 4 : 0);
     WsOffsets o{o_x, o_h, o_ao, o_qkv, o_hid, o_xb, o_dec, o_part, o_dump, o_hf, off, o_sk, part_bytes != 0, m->fused_qkv, m->fused_qa};
+    o.bytes = off;
     o.part_bytes = part_bytes;
+    o.tap = o_tap; o.has_tap = has_tap;
     return o;
 }
 // exchange the model's workspace pointers with the second chain's (the caller swaps the context's step state too): the launch sequence of a step is
@@ -447,7 +453,7 @@ void swap_chain(dd_model* m) {
     WsPtrs& w = m->ws2;
     std::swap(m->x, w.x); std::swap(m->h, w.h); std::swap(m->ao, w.ao); std::swap(m->qkv, w.qkv); std::swap(m->hid, w.hid);
     std::swap(m->xb, w.xb); std::swap(m->dec, w.dec); std::swap(m->skips, w.skips); std::swap(m->mlp_partial, w.mlp_partial);
-    std::swap(m->qkv_dump, w.qkv_dump); std::swap(m->hfrag, w.hfrag);
+    std::swap(m->qkv_dump, w.qkv_dump); std::swap(m->hfrag, w.hfrag); std::swap(m->ytap, w.ytap);
 }
 
 // ---- the forward: tokens -> blocks -> decoder_pred patches (m->dec) ---------------------------
@@ -509,6 +515,8 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             // stream, beside this block's norm1 / qkv / attention launches (which only read x); joined before the first launch that
             // writes x (attn.proj).  Out-blocks start with skip_linear, which overwrites x: their heads stay in line.
             const HeadW& hd = m->heads[bi];
+            // (the previous launch ran this block's skip_linear already: x holds its output, the tapped y is in ytap)
+            const float* xin = (skip_done && m->ytap) ? m->ytap : m->x;
             ee_side = !is_out && c->side && s != c->side && !c->ee_inline;
             hipStream_t hs = ee_side ? c->side : s;
             if (ee_side) {
@@ -516,11 +524,11 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_ee_fork, 0));
             }
             if (hd.wg) {   // the head's LayerNorm + decoder_pred in one exact-fp32 launch (the final head's kernel), patch rows only
-                HeadDecArgs ha{m->x, hd.wg, hd.dc, m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
+                HeadDecArgs ha{xin, hd.wg, hd.dc, m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
                 DD_HIP(c, launch_head_dec(ha, D, c->num_cus, hs));
             } else {
                 float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
-                DD_HIP(c, launch_layernorm<float>(m->x, hd.ng, hd.nb, hf, M, D, hs));
+                DD_HIP(c, launch_layernorm<float>(xin, hd.ng, hd.nb, hf, M, D, hs));
                 GemmArgs<float> g{hf, nullptr, hd.wdec, hd.bdec, m->dec, nullptr, M, m->pd, D, D, D, 0, m->pd};
                 DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, hs, c->num_cus));
             }
@@ -529,13 +537,13 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                          c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
             DD_HIP(c, launch_final(fa, hs));
             if (m->ee_type == DD_EE_ATTENTION_PROBE) {
-                DD_HIP(c, launch_ee_attn_probe(m->x, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, hs));
+                DD_HIP(c, launch_ee_attn_probe(xin, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, hs));
             } else {
                 // probe row: layer bi | timestep t | (t, layer): t is read from the step state inside the launch (a captured
                 // step replays for every t); dd_forward_early_exit has put int(t) there
                 const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
                 const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
-                DD_HIP(c, launch_ee_probe(m->x, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
+                DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
             }
             if (ee_side) DD_HIP(c, hipEventRecord(c->ev_ee_join, c->side));
         }
@@ -667,6 +675,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                     const BlockW& wn = m->blocks[bi + 1];
                     const int oi = bi - m->half_depth;                                // index of the NEXT block among the out-blocks
                     fa.skip = (const bf16_t*)m->skips[m->half_depth - 1 - oi];      // LIFO (uvit.py:374-375)
+                    if (ee) fa.y_tap = m->ytap;                                       // the next block's head / probe read y, which this launch consumes
                     fa.bskip = wn.skip_b; fa.nskip = D / 16;
                     fa.ln_out_g = wn.ln1_g; fa.ln_out_b = wn.ln1_b; fa.ln_out = (bf16_t*)h;
                     h_ready = true; skip_done = true;
@@ -1088,7 +1097,7 @@ int dd_model_finalize(dd_model* m, int precision) {
     // fused block tail (mlp_fused.hip): bf16 mode only (development A/B runs can switch it off: dd_dev_set_flags)
     m->fused_mlp = precision == DD_PREC_BF16 && mlp_fused_supported(D, hid) && !(c->dev_flags & DD_DEV_NO_FUSED_MLP);
     m->fused_proj = m->fused_mlp && D % 128 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_PROJ);
-    m->fused_skip = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);
+    m->fused_skip = m->fused_proj && (hid / 32) % 2 == 0 && !(c->dev_flags & DD_DEV_NO_FUSED_SKIP);     // (early-exit models too: y leaves through MlpFusedArgs::y_tap)
     m->fused_qkv = m->fused_proj && m->ee_type < 0 && (hid / 32) % 2 == 0 && !m->cfg.qkv_bias && !(c->dev_flags & DD_DEV_NO_FUSED_QKV);
     // (early-exit models too: their heads and probes read the residual stream between blocks, which this launch does not touch)
     // (embed_dim 768 / 1024 too, which have no fused block tail: their norm1 launch writes the fragment order, the qkv tensor is gone)
@@ -1297,7 +1306,7 @@ int dd_model_finalize(dd_model* m, int precision) {
         WsPtrs w;
         bind_ws(m->wsoff, m->wsarena, w);
         m->x = w.x; m->h = w.h; m->ao = w.ao; m->qkv = w.qkv; m->hid = w.hid; m->xb = w.xb; m->dec = w.dec; m->skips = w.skips;
-        m->mlp_partial = w.mlp_partial; m->qkv_dump = w.qkv_dump; m->hfrag = w.hfrag;
+        m->mlp_partial = w.mlp_partial; m->qkv_dump = w.qkv_dump; m->hfrag = w.hfrag; m->ytap = w.ytap;
     }
     m->mlp_partial_bytes = m->wsoff.part_bytes;
 

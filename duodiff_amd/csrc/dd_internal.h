@@ -140,6 +140,8 @@ struct MlpFusedArgs {
     int n_main, n_extra;   // B * tok_n patch rows (main tiles), B * tok_e extra rows (hidden-split tiles)
     int tiles_main, tiles_left, groups, cpg;
     int prows;             // rows per hidden-split tile (32, 64 or 128: whole waves)
+    float* y_tap = nullptr; // SKIP launches of early-exit models: the block output y (fp32 [Mp, D]) is stored here before skip_linear replaces it in xres -- the
+                           // patch rows by the main tiles, the extra-token rows by the reduce launch (the next block's output head and probe read y)
     int reduce_set = 0;    // launch_mlp_reduce: x = b2 + slabs instead of x += (the extra-token rows of a row-resident skip_linear; of a block tail with the
                            // projection in front: the first hidden group's slab carries x + proj(ao) + b)
 };

@@ -267,7 +267,7 @@ struct MlpCfg {
 // every other block: the qkv blocks close the image) into two alternating VGPR accumulators -- tile t-1 is converted to bf16
 // and stored (head-major, 64 contiguous bytes per row and phase) in the second half of phase t, so 100 MB of qkv leave the
 // chip under MFMA work -- and only then the fp32 rows x (and their bf16 copy) are stored.
-template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false, bool QKV = false>
+template <int D, bool LNIN, bool PARTIAL, bool PROJ, bool SKIP = false, bool QKV = false, bool TAP = false>
 __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, const int tile_idx, const int c0, int c1, const int slab) {
     using C = MlpCfg<D>;
     static_assert(!PROJ || (LNIN && C::NT % 4 == 0), "proj fusion: the LayerNorm-in kernel, D % 128 == 0");
@@ -685,6 +685,11 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
             const int hs = half_of();
             const float* lb2s = vecs + 4 * D + 4 * hs;
             const float* lbsk = vecs + 6 * D + 4 * hs;
+            // TAP (early-exit models: an instantiation of its own -- the stores' address registers would spill inside the product's SKIP phases):
+            // y leaves for the next block's output head before skip_linear replaces it
+            bool tap_ok = false;
+            float* tap = nullptr;
+            if constexpr (TAP) { tap = a.y_tap + row_of(tap_ok) * D + 4 * hs; }
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 acc_pin(Y[t]);
@@ -698,6 +703,7 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
                         const int col = 16 * ks + 8 * gq, g = 2 * kq + gq;
                         f32x4 q = {yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]};
                         q += *reinterpret_cast<const f32x4*>(lb2s + col);
+                        if constexpr (TAP) { if (tap_ok) *reinterpret_cast<f32x4*>(tap + col) = q; }
                         u[2 * gq] = pack2(q[0], q[1]);
                         u[2 * gq + 1] = pack2(q[2], q[3]);
                     }
@@ -983,11 +989,11 @@ __device__ __forceinline__ void mlp_body(const MlpFusedArgs& a, char* smem, cons
 // Either way an optional second LayerNorm (the NEXT block's norm1, models/uvit.py:206) of the updated rows is written
 // as bf16 from the epilogue (a.ln_out), so neither LayerNorm of a block needs a launch or an HBM round trip of x.
 // Workgroups [0, tiles_main) take a main tile each; the rest are the hidden-split workgroups of the extra-token tiles.
-template <int D, bool LNIN, bool PROJ, bool SKIP = false, bool QKV = false>
+template <int D, bool LNIN, bool PROJ, bool SKIP = false, bool QKV = false, bool TAP = false>
 __global__ void __launch_bounds__(256) mlp_fused_kernel(const MlpFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.tiles_main) {
-        mlp_body<D, LNIN, false, PROJ, SKIP, QKV>(a, smem, blockIdx.x, 0, a.nchunks, 0);
+        mlp_body<D, LNIN, false, PROJ, SKIP, QKV, TAP>(a, smem, blockIdx.x, 0, a.nchunks, 0);
     } else {
         const int e = blockIdx.x - a.tiles_main;
         const int lt = e / a.groups, g = e - lt * a.groups;
@@ -1037,6 +1043,10 @@ __global__ void __launch_bounds__(256) mlp_reduce_kernel(const MlpFusedArgs a) {
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < VPL; ++e) { xv[e] = a.reduce_set ? acc[e] : xv[e] + acc[e]; xp[e] = xv[e]; sum += xv[e]; }
+    if (a.y_tap) {
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) a.y_tap[row * D + col + e] = xv[e];
+    }
     if (a.out) {
 #pragma unroll
         for (int e = 0; e < VPL; ++e) a.out[row * a.ldo + col + e] = f2bf(xv[e]);
@@ -1259,6 +1269,7 @@ hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
     const int grid = a.tiles_main + a.tiles_left * a.groups;
     if (a.nskip > 0 && (a.nproj <= 0 || a.nskip != D / 16 || !a.skip || !a.bskip || (!a.ln_out && a.nqkv <= 0) || a.nchunks % 2)) return hipErrorInvalidValue;
     if (a.nqkv > 0 && a.nproj <= 0) return hipErrorInvalidValue;
+    if (a.y_tap && (a.nskip <= 0 || a.nqkv > 0)) return hipErrorInvalidValue;      // (the tap rides on the SKIP launches of early-exit models)
     if (a.ln_out_frag && (!a.ln_out || a.nqkv > 0 || a.tok_n % 32)) return hipErrorInvalidValue;   // (whole 32-row groups of patch rows per wave)
     if (a.nproj > 0) {
         if constexpr (D % 128 == 0) {
@@ -1267,7 +1278,8 @@ hipError_t launch_d(const MlpFusedArgs& a, hipStream_t s) {
                 if (a.nqkv != 3 * D / 32 || !a.qkv_out || !a.qkv_dump || !a.ln_out_g || !a.ln_out_b || a.hm.L != a.tok_l || a.nchunks % 2) return hipErrorInvalidValue;
                 if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true, true>), dim3(grid), dim3(256), lds, s, a);
                 else hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, false, true>), dim3(grid), dim3(256), lds, s, a);
-            } else if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+            } else if (a.nskip > 0 && a.y_tap) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true, false, true>), dim3(grid), dim3(256), lds, s, a);
+            else if (a.nskip > 0) hipLaunchKernelGGL((mlp_fused_kernel<D, true, true, true>), dim3(grid), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((mlp_fused_kernel<D, true, true>), dim3(grid), dim3(256), lds, s, a);
         } else {
             return hipErrorInvalidValue;
@@ -1421,6 +1433,9 @@ hipError_t init_mlp_fused_kernels() {
                                     MlpCfg<DV>::RING + bias);                                                \
         if (e == hipSuccess)                                                                                 \
             e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    MlpCfg<DV>::RING + bias);                                                \
+        if (e == hipSuccess)                                                                                 \
+            e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     MlpCfg<DV>::RING + bias);                                                \
         if (e == hipSuccess)                                                                                 \
             e = hipFuncSetAttribute((const void*)mlp_fused_kernel<DV, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -21,7 +21,7 @@ def main():
     lines = open(out).read().split("\n")
     rc = 0
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN2dd\S*mlp_fused_kernelILi512E\S*:", l)]
-    assert len(starts) == 6, "expected the plain, LayerNorm-in, + proj, + skip, + qkv and + skip + qkv instantiations"
+    assert len(starts) == 7, "expected the plain, LayerNorm-in, + proj, + skip, + skip + y-tap (early exit), + qkv and + skip + qkv instantiations"
     for start in starts:
         end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))   # (a kernel may have several s_endpgm)
         body = lines[start:end]
