@@ -125,6 +125,8 @@ struct dd_model {
     std::vector<HeadW> heads;             // head i is applied to the input of block i
     const float *probe_w = nullptr, *probe_b = nullptr;   // [n_probe, D], [n_probe]
     std::vector<AttnProbeW> attn_probes;                  // DD_EE_ATTENTION_PROBE: one per layer
+    bool ee_conv_stride_ok = false;                       // the heads' conv weights / biases sit at a constant stride in the weight arena (one batched conv launch)
+    long long ee_wconv_stride = 0, ee_bconv_stride = 0;
     bool fused_mlp = false;               // bf16 mode, D in {64,128,256,512}: fc1+GELU+fc2+residual in one launch
     bool fused_proj = false;              // ... and attn.proj + residual in front of it (D % 128 == 0): patch rows only
     bool fused_skip = false;              // ... and the NEXT block's skip_linear + norm1 behind it (mid / out blocks; early-exit models tap y on the way,
@@ -506,6 +508,17 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
     bool qkv_done = false;  // ... and qkv already holds that block's attn.qkv output (ditto)
     bool qa_ready = ln1_done;  // ... or only the extra-token rows of it: the patch rows' qkv is computed inside the attention launch
     bool ee_side = false;   // this block's early-exit head / probe launches are in flight on the side stream
+    // Early-exit heads: every layer's LayerNorm + decoder_pred launch writes its own slice of a [depth][B L, pd] buffer and every MLP probe's row
+    // launch its own [B, L] slice; ONE unpatchify / conv launch and ONE probe reduce launch behind the last block finish all layers (the
+    // per-layer arithmetic is unchanged; 2 x 12 launches less on each step's critical path).  The buffers live in the MLP hidden buffer, which
+    // the fused block tail never touches; models on the GEMM path (and images below one 16 x 16 tile) keep the per-layer launches.
+    float* ee_dec_all = nullptr;
+    float* ee_srow_all = nullptr;
+    if (ee && sizeof(T) == 2 && m->fused_mlp && m->ee_conv_stride_ok && m->heads[0].wg && m->cfg.img_size >= 16 &&
+        (size_t)nb * ((size_t)M * m->pd + (size_t)B * L) * sizeof(float) <= (size_t)Mp * m->hid_ld * m->esize) {
+        ee_dec_all = (float*)m->hid;
+        ee_srow_all = ee_dec_all + (size_t)nb * M * m->pd;
+    }
     for (int bi = 0; bi < nb; ++bi) {
         const BlockW& w = m->blocks[bi];
         const bool is_in = bi < m->half_depth, is_out = bi > m->half_depth;
@@ -524,7 +537,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_ee_fork, 0));
             }
             if (hd.wg) {   // the head's LayerNorm + decoder_pred in one exact-fp32 launch (the final head's kernel), patch rows only
-                HeadDecArgs ha{xin, hd.wg, hd.dc, m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
+                HeadDecArgs ha{xin, hd.wg, hd.dc, ee_dec_all ? ee_dec_all + (size_t)bi * M * m->pd : m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
                 DD_HIP(c, launch_head_dec(ha, D, c->num_cus, hs));
             } else {
                 float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
@@ -533,9 +546,11 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, launch_gemm<float>(g, EPI_BIAS_SET, hs, c->num_cus));
             }
             const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
-            FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
-                         c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
-            DD_HIP(c, launch_final(fa, hs));
+            if (!ee_dec_all) {
+                FinalArgs fa{m->dec, hd.wconv, hd.bconv, nullptr, nullptr, ee->outs + (long long)bi * B * chw, nullptr, c->st,
+                             c->coef, B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
+                DD_HIP(c, launch_final(fa, hs));
+            }
             if (m->ee_type == DD_EE_ATTENTION_PROBE) {
                 DD_HIP(c, launch_ee_attn_probe(xin, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, hs));
             } else {
@@ -543,7 +558,8 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 // step replays for every t); dd_forward_early_exit has put int(t) there
                 const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
                 const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
-                DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
+                if (ee_srow_all) DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, nullptr, ee_srow_all + (size_t)bi * B * L, B, L, D, c->st, t_mul, add, hs));   // rows only: reduced behind the last block
+                else DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
             }
             if (ee_side) DD_HIP(c, hipEventRecord(c->ev_ee_join, c->side));
         }
@@ -777,6 +793,15 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             g.tile128 = tile128(D, m->hidden, m->hidden);
             DD_HIP(c, launch_gemm<T>(g, EPI_BIAS_RESID, s, c->num_cus));
         }
+    }
+    if (ee_dec_all) {     // every layer's unpatchify + conv in one launch (layer i: images [i B, (i + 1) B) of nb B, its own conv weights), every MLP probe's mean in one
+        const long long chw = (long long)m->cfg.in_chans * m->cfg.img_size * m->cfg.img_size;
+        FinalArgs fa{ee_dec_all, m->heads[0].wconv, m->heads[0].bconv, nullptr, nullptr, ee->outs, nullptr, c->st,
+                     c->coef, nb * B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
+        fa.layer_B = B; fa.w_stride = m->ee_wconv_stride; fa.b_stride = m->ee_bconv_stride;
+        DD_HIP(c, launch_final(fa, s));
+        if (m->ee_type != DD_EE_ATTENTION_PROBE) DD_HIP(c, launch_ee_probe_reduce(ee_srow_all, ee->cls, nb * B, L, s));
+        (void)chw;
     }
     // output head (uvit.py:377-378): final LayerNorm in fp32 into scratch (the MLP hidden buffer is
     // free here), then decoder_pred as an exact-fp32 MFMA GEMM in BOTH precision modes, so eps is
@@ -1292,6 +1317,12 @@ int dd_model_finalize(dd_model* m, int precision) {
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
     for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv), fused_head ? F(o.wg) : nullptr, fused_head ? F(o.dc) : nullptr});
+    if (m->heads.size() >= 2) {
+        m->ee_wconv_stride = m->heads[1].wconv - m->heads[0].wconv; m->ee_bconv_stride = m->heads[1].bconv - m->heads[0].bconv;
+        m->ee_conv_stride_ok = true;
+        for (size_t i = 0; i < m->heads.size(); ++i)
+            if (m->heads[i].wconv != m->heads[0].wconv + (long long)i * m->ee_wconv_stride || m->heads[i].bconv != m->heads[0].bconv + (long long)i * m->ee_bconv_stride) m->ee_conv_stride_ok = false;
+    }
     if (m->ee_type >= 0 && m->ee_type != DD_EE_ATTENTION_PROBE) { m->probe_w = F(o_pw); m->probe_b = F(o_pb); }
     for (const AttnProbeOff& o : aoffs) m->attn_probes.push_back(AttnProbeW{F(o.u), F(o.wvt), F(o.bv), F(o.w0t), F(o.b0), F(o.w2), F(o.b2)});
     if (fused_head) { m->wdec_g = F(o_wg); m->dec_c = F(o_dc); }

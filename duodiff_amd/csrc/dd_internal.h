@@ -266,6 +266,8 @@ struct FinalArgs {
     int advance;
     const AffineRow* atab; // or null.  Set: st->t is a STEP INDEX k into this table; the update is a x + b eps + c z with row k,
                            // and advance hands row k + 1's timestep to the next step (the table holds one row more than steps)
+    int layer_B = 0;       // > 0: the B "images" are layer_B images of B / layer_B early-exit layers, one after the other (dec, eps_out contiguous that way);
+    long long w_stride = 0, b_stride = 0;   //   layer i convolves with wconv + i * w_stride / bconv + i * b_stride (floats): ONE launch for every layer's head
     int b0 = 0;            // index of this launch's first image within the whole batch (a half-batch chain of dd_sample): only the
                            // Philox pixel ids depend on it, so that a chain draws the z the undivided batch would
 };
@@ -304,6 +306,7 @@ hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out,
 // probe row = (t_mul ? st->t_final * t_mul : 0) + add of the [n_probe, D] / [n_probe] tables; srow: [B, L] fp32 scratch (the rows' sigmoids)
 hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, float* srow, int B, int L, int D,
                            const StepState* st, int t_mul, int add, hipStream_t s);
+hipError_t launch_ee_probe_reduce(const float* srow, float* out, int rows, int L, hipStream_t s);   // out == nullptr above: the rows only; this finishes any number of (layer, image) rows
 // st != null: idx / err_mean are [1000, B] / [1000, depth] tables and row st->t_final is written
 // a half-batch chain (dd_sample_early_exit): B = the chain's images, idx rows are idx_stride = the whole batch wide and the chain writes from
 // column idx_col0 on; sums: err_mean receives the plain per-layer SUM over the chain's images (launch_ee_mean_combine joins the chains)

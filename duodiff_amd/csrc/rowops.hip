@@ -605,13 +605,16 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
         }
     }
     float wc[4][4][9], bc[4];
+    const int layer = a.layer_B > 0 ? b / a.layer_B : 0;      // (early-exit heads batched into one launch: this image's layer)
+    const float* wconv = a.wconv + layer * a.w_stride;
+    const float* bconv = a.bconv + layer * a.b_stride;
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
-        bc[co] = co < C ? a.bconv[co] : 0.f;
+        bc[co] = co < C ? bconv[co] : 0.f;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wc[co][ci][k] = (co < C && ci < C) ? a.wconv[(co * C + ci) * 9 + k] : 0.f;
+            for (int k = 0; k < 9; ++k) wc[co][ci][k] = (co < C && ci < C) ? wconv[(co * C + ci) * 9 + k] : 0.f;
     }
     for (int idx = tid; idx < 18 * 18; idx += 256) {
         const int hy = idx / 18, hx = idx % 18;
@@ -1160,7 +1163,12 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
 hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, float* srow, int B, int L, int D,
                            const StepState* st, int t_mul, int add, hipStream_t s) {
     hipLaunchKernelGGL(ee_probe_rows_kernel, dim3(B, 8), dim3(256), 0, s, x, w_base, bias_base, srow, L, D, st, t_mul, add);
-    hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, srow, out, B, L);
+    if (out) hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, srow, out, B, L);     // (out == null: launch_ee_probe_reduce later, for several layers at once)
+    return hipGetLastError();
+}
+// the reduce half alone, for `rows` (image, layer) rows of L sigmoids each: srow [rows, L] -> out [rows], the per-row arithmetic of launch_ee_probe
+hipError_t launch_ee_probe_reduce(const float* srow, float* out, int rows, int L, hipStream_t s) {
+    hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((4 * rows + 255) / 256), dim3(256), 0, s, srow, out, rows, L);
     return hipGetLastError();
 }
 hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s) {
