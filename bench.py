@@ -498,6 +498,15 @@ def main():
                              "cu_share": cu_share,
                              "frac_of_the_cus_it_holds": fl / 2 / (ms_ch * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS * cu_share),
                              "ms_per_launch_source": "measured live (hipEvents on both chains' streams, eager steps)"},
+                         # the block tail is power-limited: constants of the committed in-kernel stamp run (a diagnostic variant build; not measured here)
+                         "power_limit": None if kind != "block_tail" else {
+                             "in_kernel_clock_mhz": {"all_cus_random_operands": 1680, "all_cus_zero_operands": 2380, "half_the_cus_random_operands": 2370},
+                             "cycles_per_workgroup": 255000, "chunk_loop_cycles_per_chunk": 2244, "mfma_cycles_per_chunk": 2048,
+                             "chunk_loop_frac_of_the_pipe_rate_in_cycles": 2048.0 / 2244.0,
+                             "us_per_launch_zero_operands_same_cycles": 113.0,
+                             "source": "profiles/r05/power_probe.txt, block_tail_energy_ablations.txt (tools/power_probe.py on the stamped variant of mlp_fused_kernel<512, LN, PROJ>; "
+                                       "s_memtime / s_memrealtime per workgroup): the launch's cycles are worth 0.55 of the roof at the nominal clock; on random operands with "
+                                       "all 256 CUs in the kernel the chip holds 1.66-1.69 GHz"},
                          "sustained_mfma_tflops_random_operands": 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
                                            "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
