@@ -467,7 +467,8 @@ struct QkvAttnArgs {
 // LDS behind the K / V images: px = the extra rows' partial q / k / v sums [8 waves][6 tiles][2 rows][32 columns] fp32 (the split
 // chunk's [8 waves][2 queries][64 d, max, sum] fp32 reuses its start later) | hxl = the extra rows of h [2][D] bf16 | qxl = their q [2][64] bf16
 constexpr int kQaPxBytes = 8 * 6 * 2 * 32 * 4;
-constexpr int kQaHxBytes = 2 * 1024 * 2;             // two rows of D <= 1024 bf16
+constexpr int kQaHxPad = 64;                         // the second extra row starts 16 banks off the first: a lane group of the 16x16x32 B-operand read holds both rows at two 16-byte offsets
+constexpr int kQaHxBytes = 2 * (1024 * 2 + kQaHxPad);  // two rows of D <= 1024 bf16
 constexpr int kQaAuxBytes = kQaPxBytes + kQaHxBytes + 256;
 constexpr int kQaKQ = 8;                             // k-steps per slice of the k range
 constexpr int kQaBlk = 2 * kQaKQ * 1024;             // one weight block = (slice, tile pair): 2 x 8 k-steps x 1 KB fragments
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     if (a.hx) {
         for (int i = tid; i < E * (D / 8); i += 512) {
             const int e = i / (D / 8), cch = i % (D / 8);
-            *reinterpret_cast<f32x4*>(hxl + e * (D * 2) + cch * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + e) * D + cch * 8);
+            *reinterpret_cast<f32x4*>(hxl + e * (D * 2 + kQaHxPad) + cch * 16) = *reinterpret_cast<const f32x4*>(a.hx + ((long long)b * L + e) * D + cch * 8);
         }
     } else if (wave < E) {     // wave e normalises extra row e (two-pass statistics, fp32): D / 64 columns per lane
         constexpr int NV = D / 256;
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
         for (int v = 0; v < NV; ++v) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + lane * (D / 64) + 4 * v), c0 = *reinterpret_cast<const f32x4*>(a.ln_b + lane * (D / 64) + 4 * v);
             const f32x4 y = xv[v] * rstd * g + c0;
-            *reinterpret_cast<uint2*>(hxl + wave * (D * 2) + (lane * (D / 64) + 4 * v) * 2) = uint2{pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3])};
+            *reinterpret_cast<uint2*>(hxl + wave * (D * 2 + kQaHxPad) + (lane * (D / 64) + 4 * v) * 2) = uint2{pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3])};
         }
     }
     for (int i = tid; i < (kLP - 256 - E) * 16; i += 512) {
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     for (int j = 0; j < 6; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int xg = lane >> 4, xn = lane & 15;
     const int wx16 = (2 * (wave >> 1) + (xg >> 1)) * 1024 + ((16 * (wave & 1) + xn) + 32 * (xg & 1)) * 16;
-    const char* hx16 = hxl + (xn < E ? xn : 0) * (D * 2) + (wave >> 1) * 64 + xg * 16;
+    const char* hx16 = hxl + (xn < E ? xn : 0) * (D * 2 + kQaHxPad) + (wave >> 1) * 64 + xg * 16;
     bf16x8 wq[4];            // the fragment queue: fragment g of the stream (block g >> 4, fragment g & 15) is read four MFMAs ahead
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // blocks 0..2, slice 0 of the rows, hxl, the zero rows
 #pragma unroll

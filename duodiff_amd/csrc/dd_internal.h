@@ -266,10 +266,11 @@ struct FinalArgs {
     int advance;
     const AffineRow* atab; // or null.  Set: st->t is a STEP INDEX k into this table; the update is a x + b eps + c z with row k,
                            // and advance hands row k + 1's timestep to the next step (the table holds one row more than steps)
-    int layer_B = 0;       // > 0: the B "images" are layer_B images of B / layer_B early-exit layers, one after the other (dec, eps_out contiguous that way);
-    long long w_stride = 0, b_stride = 0;   //   layer i convolves with wconv + i * w_stride / bconv + i * b_stride (floats): ONE launch for every layer's head
     int b0 = 0;            // index of this launch's first image within the whole batch (a half-batch chain of dd_sample): only the
                            // Philox pixel ids depend on it, so that a chain draws the z the undivided batch would
+    // (the fields below are set by name, never positionally: the aggregate initialisers of the step launches end at b0)
+    int layer_B = 0;       // > 0: the B "images" are layer_B images of B / layer_B early-exit layers, one after the other (dec, eps_out contiguous that way);
+    long long w_stride = 0, b_stride = 0;   //   layer i convolves with wconv + i * w_stride / bconv + i * b_stride (floats): ONE launch for every layer's head
 };
 hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 

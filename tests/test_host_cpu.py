@@ -199,3 +199,12 @@ def test_bench_roofline_leg_follows_the_committed_kernel_table():
             assert kind in Model.PROFILE_KINDS and 0 < b.cu_share_half_batch(kind, mp, B) <= 1.0
     lib = _lib.load()
     assert lib.dd_profile_select(None, 0) == _lib.DD_ERR_INVALID      # (a null context is refused: the symbol exists and checks its arguments)
+
+
+def test_documents_quote_the_committed_profiles():
+    """README.md and DESIGN.md carry ONE generated performance block (tools/perf_tables.py: the driver's BENCH_rNN.json records + the newest
+    profiles/rNN collection); it must be what the files say (no number in the documents that a file under profiles/ contradicts)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "perf_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
