@@ -524,12 +524,17 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     const int half = lane >> 5, r32 = lane & 31;
     const int L = a.L, E = a.E;
 
-    const char* wsrc = reinterpret_cast<const char*>(a.wimg) + (size_t)hh * NB * kQaBlk + lane * 16;
+    // LDS-DMA in the scalar-base form (uniform 64-bit base in SGPRs + one 32-bit lane offset), written as asm: the builtin makes a 64-bit VGPR address
+    // pair of it, and that form serialises with the MFMAs of BOTH waves of the SIMD (75 cycles per request, profiles/r05/dma_mfma_probe_roles.txt)
+    const char* wsrc = reinterpret_cast<const char*>(a.wimg) + (size_t)hh * NB * kQaBlk;
+    const unsigned lane16 = lane * 16;
     auto dma_block = [&](int bb) {      // block bb -> ring slot bb & 3: two 1 KB pieces per wave
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pc = wave * 2 + i;
-            __builtin_amdgcn_global_load_lds((qa_gptr_t)(wsrc + (size_t)bb * kQaBlk + pc * 1024), (qa_lptr_t)(ring + (bb & 3) * kQaBlk + pc * 1024), 16, 0, 0);
+            const char* sb = wsrc + (size_t)bb * kQaBlk + pc * 1024;
+            const unsigned lds = lds_addr_of(ring + (bb & 3) * kQaBlk + pc * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane16), "s"(sb) : "memory", "m0");
         }
     };
     dma_block(0);
@@ -539,7 +544,8 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
     // ---- this wave's 32 rows of h, part 0, as B fragments (k-step ks: k = 16 ks + 8 half .. + 7): the producer left them in exactly
     // this order ([32-row group][k-step][lane] x 16 bytes: MlpFusedArgs::ln_out_frag / launch_layernorm_frag), 1 KB per load instruction
     const int row = 32 * wave + r32;                                   // image row = patch index
-    const bf16x8* hfr = reinterpret_cast<const bf16x8*>(a.h) + ((long long)b * 8 + wave) * KS * 64 + lane;
+    const bf16x8* hfr_u = reinterpret_cast<const bf16x8*>(a.h) + ((long long)b * 8 + wave) * KS * 64;     // wave-uniform: the lane's 16 bytes ride in the 32-bit offset
+    const bf16x8* hfr = hfr_u + lane;
     bf16x8 xs[2][kQaKQ];                                               // slice q lives in set q & 1
 #pragma unroll
     for (int ks = 0; ks < kQaKQ; ++ks) xs[0][ks] = hfr[ks * 64];
@@ -613,7 +619,7 @@ __global__ void __launch_bounds__(512, 1) qkv_attention_kernel(const QkvAttnArgs
                 if constexpr (q + 1 < NS) {  // the next slice's rows into the other set (last read in the block before this one)
 #pragma unroll
                     for (int ks = 0; ks < kQaKQ; ++ks)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xs[S ^ 1][ks]) : "v"(hfr + ((q + 1) * kQaKQ + ks) * 64) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xs[S ^ 1][ks]) : "v"(lane16), "s"(hfr_u + ((q + 1) * kQaKQ + ks) * 64) : "memory");
                 }
             }
             const char* wb = ring + (bb & 3) * kQaBlk + lane * 16;

@@ -33,6 +33,13 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 // exact-erf GELU (nn.GELU default), fp32 parity mode: libm erff.  (The bf16 mode uses the polynomial of gelu_erf4.)
 __device__ __forceinline__ float gelu_erf_f32(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+// The same piece in the scalar-base form: uniform 64-bit base (SGPRs) + a 32-bit lane offset, M0 = the piece's LDS address.  Written as asm: the builtin turns
+// base + offset into a 64-bit VGPR address pair (checked in the ISA), and that form serialises with the SIMD's MFMAs (profiles/r05/dma_mfma_probe_roles.txt).
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, const void* lds_dst) {
+    const unsigned lds = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
 // Stage ROWS x 128 B into a lane-linear LDS tile with the source-side chunk swizzle.
 // `g` points at (row 0, this k-tile's first byte); rows >= row_limit are clamped (N guard).
 template <int ROWS, int NWAVES>
@@ -382,7 +389,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
 #pragma unroll
         for (int inst = 0; inst < 4; ++inst) {
             const unsigned x = (inst & 1) ? 64u : 0u;
-            glds16(a_rows + (long long)(inst * 8) * sa1 + (voff_a ^ x), at + (wave * 4 + inst) * 1024);
+            glds16s(a_rows + (long long)(inst * 8) * sa1, voff_a ^ x, at + (wave * 4 + inst) * 1024);
         }
         if (wave == 0 && part.e > 0) {
             // 8 tail rows of this tile -> LDS rows 256..263 (row index 256 + lr: even-inst swizzle)
@@ -393,7 +400,7 @@ gemm256_kernel(const GemmArgs<bf16_t> a, const Part256 part) {
 #pragma unroll
         for (int inst = 0; inst < 4; ++inst) {
             const unsigned x = (inst & 1) ? 64u : 0u;
-            glds16(w_rows + (long long)(inst * 8) * sw + (voff_w ^ x), at + A_BYTES + (wave * 4 + inst) * 1024);
+            glds16s(w_rows + (long long)(inst * 8) * sw, voff_w ^ x, at + A_BYTES + (wave * 4 + inst) * 1024);
         }
     };
 

@@ -46,9 +46,11 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
-// Same, addressed as (uniform base in SGPRs) + (32-bit lane offset): the base is made opaque so that hipcc keeps the
-// scalar-base form of the instruction instead of folding the lane offset into one 64-bit VGPR pointer per request
-// (16 pairs live across the hot loop otherwise -- the registers the loop does not have).
+// Same, addressed as (uniform base) + (32-bit lane offset): the base is made opaque so that hipcc does not hoist one 64-bit VGPR pointer per
+// request out of the hot loop (16 pairs live across it otherwise -- the registers the loop does not have).  What it emits is still the VGPR-pair
+// form `global_load_lds_dwordx4 v[n:n+1], off offset:imm` (one address computation per four requests through the immediate offset); the true
+// scalar-base form `voff, s[base:base+1]` needs asm (rowlin.hip, gemm.hip, attention.hip use it) and measured neutral HERE (2 281 vs 2 246 cycles
+// per chunk, 156.1 vs 156.3 us per launch, profiles/r05/ab_round5.txt): this loop hides its request issue already.
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     asm volatile("" : "+s"(p));
     return p;

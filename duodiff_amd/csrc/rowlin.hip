@@ -37,6 +37,11 @@ __device__ __forceinline__ unsigned rl_pack2(float lo, float hi) {
 }
 
 __device__ __forceinline__ unsigned rl_lds(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+// one 1 KB LDS-DMA piece in the scalar-base form: uniform 64-bit base (SGPRs) + a 32-bit lane offset, M0 = the piece's LDS address.  Written as asm: the
+// builtin turns base + offset into a 64-bit VGPR address pair, and that form serialises with the SIMD's MFMAs (profiles/r05/dma_mfma_probe_roles.txt).
+__device__ __forceinline__ void rl_dma(const char* sbase, unsigned voff, const void* lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(rl_lds(lds_dst)), "v"(voff), "s"(sbase) : "memory", "m0");
+}
 template <int OFF>
 __device__ __forceinline__ void rl_read(bf16x8& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
@@ -88,12 +93,13 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
     };
 
     // LDS-DMA of the weights of k-step ks -> ring slot ks & 3: 24 pieces, 6 per wave
-    const char* wsrc = a.wimg + (size_t)ks0 * kRlBlk + lane * 16;
+    const char* wsrc = a.wimg + (size_t)ks0 * kRlBlk;
+    const unsigned lane16 = lane * 16;
     auto dma_w = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int pc = wave * 6 + i;
-            __builtin_amdgcn_global_load_lds((rl_gptr_t)(wsrc + (size_t)ks * kRlBlk + pc * 1024), (rl_lptr_t)(ring + (ks & 3) * kRlBlk + pc * 1024), 16, 0, 0);
+            rl_dma(wsrc + (size_t)ks * kRlBlk + pc * 1024, lane16, ring + (ks & 3) * kRlBlk + pc * 1024);
         }
     };
     // LDS-DMA of the rows' operand, group g (k = 64 g .. 64 g + 63) -> A buffer g % 3: 16 pieces of 8 rows x 128 B, 4 per wave; the lane
@@ -114,18 +120,18 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((rl_gptr_t)((g < g_split ? abase_1 : abase_2) + (arows[i] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
+            rl_dma(g < g_split ? abase_1 : abase_2, arows[i] + (unsigned)g * 128u, abuf + (g % 3) * kRlABuf + pc * 1024);
         }
     };
     // ... and one piece at a time (the loop spreads a k-step's requests over its MFMA gaps: an LDS-DMA instruction costs 60-185 cycles of
     // issue, a burst of 10 stalls the wave for a whole k-step's worth of MFMA time)
     auto dma_w1 = [&](int ks, int j) {
         const int pc = wave * 6 + j;
-        __builtin_amdgcn_global_load_lds((rl_gptr_t)(wsrc + (size_t)ks * kRlBlk + pc * 1024), (rl_lptr_t)(ring + (ks & 3) * kRlBlk + pc * 1024), 16, 0, 0);
+        rl_dma(wsrc + (size_t)ks * kRlBlk + pc * 1024, lane16, ring + (ks & 3) * kRlBlk + pc * 1024);
     };
     auto dma_a1 = [&](int g, int j) {
         const int pc = wave * 4 + j;
-        __builtin_amdgcn_global_load_lds((rl_gptr_t)((g < g_split ? abase_1 : abase_2) + (arows[j] + (unsigned)g * 128u)), (rl_lptr_t)(abuf + (g % 3) * kRlABuf + pc * 1024), 16, 0, 0);
+        rl_dma(g < g_split ? abase_1 : abase_2, arows[j] + (unsigned)g * 128u, abuf + (g % 3) * kRlABuf + pc * 1024);
     };
     // prologue: A groups 0, 1; weights of k-steps 0, 1, 2
     dma_a(0);
@@ -214,10 +220,10 @@ __global__ void __launch_bounds__(256) rowlin768_kernel(const RowLinArgs a) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) *reinterpret_cast<f32x4*>(strip + r32 * kPitch + (h * 32 + j) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
-            const char* src = reinterpret_cast<const char*>(a.xres + 256 * p) + lane * 16;
+            const char* src = reinterpret_cast<const char*>(a.xres + 256 * p);
             for (int i = 0; i < nvalid; ++i) {
                 const long long ri = row0w + i < rows_all ? row0w + i : rows_all - 1;
-                __builtin_amdgcn_global_load_lds((rl_gptr_t)(src + ri * (kRlD * 4)), (rl_lptr_t)(strip + i * kPitch), 16, 0, 0);
+                rl_dma(src + ri * (kRlD * 4), lane * 16, strip + i * kPitch);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
