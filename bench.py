@@ -507,7 +507,7 @@ def main():
                              "source": "profiles/r05/power_probe.txt, block_tail_energy_ablations.txt (tools/power_probe.py on the stamped variant of mlp_fused_kernel<512, LN, PROJ>; "
                                        "s_memtime / s_memrealtime per workgroup): the launch's cycles are worth 0.55 of the roof at the nominal clock; on random operands with "
                                        "all 256 CUs in the kernel the chip holds 1.66-1.69 GHz"},
-                         "sustained_mfma_tflops_random_operands": 1910.0,
+                         "sustained_mfma_tflops_random_operands": 1910.0, "frac_of_sustained": ach / 1910.0,
                          "sustained_note": "constant, not measured in this run: register-only v_mfma_f32_32x32x16_bf16 loop, random operands, "
                                            "measured on MI355X (tools/mfma_peak.hip, profiles/r01/mfma_peak.txt); 2470 with constant operands"},
         }
