@@ -77,7 +77,7 @@ struct BlockW {
     const char* rls_img = nullptr;  // skip_linear weight [D, 2 D], ditto (out-blocks)
 };
 
-struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred) or null
+struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred; dc = c [pd], row sums of wg [pd]) or null
 
 struct GraphKey {
     const void* x; const void* y; int B, noise, variance, num_cus;   // num_cus: the captured persistent grids are sized from it
@@ -116,7 +116,7 @@ struct dd_model {
     const float *emb_wt = nullptr, *emb_b = nullptr, *pos = nullptr, *label = nullptr;
     const float *tm_w1t = nullptr, *tm_b1 = nullptr, *tm_w2t = nullptr, *tm_b2 = nullptr;   // time_embed MLP (mlp_time_embed)
     const float *norm_g = nullptr, *norm_b = nullptr, *wdec = nullptr, *bdec = nullptr, *wconv = nullptr, *bconv = nullptr;
-    const float *wdec_g = nullptr, *dec_c = nullptr;   // head_dec_kernel operands (decoder weight * norm gamma; bias + W . beta) or null
+    const float *wdec_g = nullptr, *dec_c = nullptr;   // head_dec_kernel operands (decoder weight * norm gamma; bias + W . beta [pd], then the row sums of wdec_g [pd]) or null
     float* x = nullptr; void* h = nullptr; void* ao = nullptr; void* qkv = nullptr; void* hid = nullptr; void* xb = nullptr;
     std::vector<void*> skips;
     float* dec = nullptr;
@@ -536,8 +536,17 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
                 DD_HIP(c, hipEventRecord(c->ev_ee_fork, s));
                 DD_HIP(c, hipStreamWaitEvent(c->side, c->ev_ee_fork, 0));
             }
+            // probe row: layer bi | timestep t | (t, layer): t is read from the step state inside the launch (a captured
+            // step replays for every t); dd_forward_early_exit has put int(t) there
+            const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
+            const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
+            bool probe_done = false;
             if (hd.wg) {   // the head's LayerNorm + decoder_pred in one exact-fp32 launch (the final head's kernel), patch rows only
                 HeadDecArgs ha{xin, hd.wg, hd.dc, ee_dec_all ? ee_dec_all + (size_t)bi * M * m->pd : m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
+                if (ee_srow_all && m->ee_type != DD_EE_ATTENTION_PROBE && head_dec_probe_supported(D)) {   // ... and the MLP probe's per-token values of the same rows
+                    ha.srow = ee_srow_all + (size_t)bi * B * L; ha.pw_base = m->probe_w; ha.pb_base = m->probe_b; ha.st = c->st; ha.t_mul = t_mul; ha.add = add;
+                    probe_done = true;
+                }
                 DD_HIP(c, launch_head_dec(ha, D, c->num_cus, hs));
             } else {
                 float* hf = (float*)m->hid;   // the MLP hidden buffer is free between blocks
@@ -553,11 +562,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             }
             if (m->ee_type == DD_EE_ATTENTION_PROBE) {
                 DD_HIP(c, launch_ee_attn_probe(xin, m->attn_probes[bi], ee->cls + (long long)bi * B, B, L, D, hs));
-            } else {
-                // probe row: layer bi | timestep t | (t, layer): t is read from the step state inside the launch (a captured
-                // step replays for every t); dd_forward_early_exit has put int(t) there
-                const int t_mul = m->ee_type == DD_EE_MLP_PER_LAYER ? 0 : m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 1 : nb;
-                const int add = m->ee_type == DD_EE_MLP_PER_TIMESTEP ? 0 : bi;
+            } else if (!probe_done) {
                 if (ee_srow_all) DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, nullptr, ee_srow_all + (size_t)bi * B * L, B, L, D, c->st, t_mul, add, hs));   // rows only: reduced behind the last block
                 else DD_HIP(c, launch_ee_probe(xin, m->probe_w, m->probe_b, ee->cls + (long long)bi * B, (float*)m->hid, B, L, D, c->st, t_mul, add, hs));   // (the MLP hidden buffer is free between blocks)
             }
@@ -1216,14 +1221,16 @@ int dd_model_finalize(dd_model* m, int precision) {
     size_t o_wg = 0, o_dc = 0;
     if (fused_head) {
         const std::vector<float>&wd = P("decoder_pred.weight"), &bd = P("decoder_pred.bias"), &ng = P("norm.weight"), &nbv = P("norm.bias");
-        std::vector<float> wg((size_t)m->pd * D), dc(m->pd);
+        std::vector<float> wg((size_t)m->pd * D), dc(2 * (size_t)m->pd);     // dc = c [pd], then the row sums of wg [pd]
         for (int r = 0; r < m->pd; ++r) {
-            double acc = bd[r];
+            double acc = bd[r], wsum = 0.0;
             for (int k = 0; k < D; ++k) {
                 wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
                 acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
+                wsum += (double)wg[(size_t)r * D + k];
             }
             dc[r] = (float)acc;
+            dc[m->pd + r] = (float)wsum;
         }
         o_wg = put_f32(wg.data(), wg.size()); o_dc = put_f32(dc.data(), dc.size());
     }
@@ -1245,14 +1252,16 @@ int dd_model_finalize(dd_model* m, int precision) {
             o.bconv = put_f32(P(p + "final_layer.bias").data(), m->cfg.in_chans);
             if (fused_head) {   // as the final head: dec = (W . diag(gamma)) xn + (b + W . beta)
                 const std::vector<float>&wd = P(p + "decoder_pred.weight"), &bd = P(p + "decoder_pred.bias"), &ng = P(p + "norm.weight"), &nbv = P(p + "norm.bias");
-                std::vector<float> wg((size_t)m->pd * D), dc(m->pd);
+                std::vector<float> wg((size_t)m->pd * D), dc(2 * (size_t)m->pd);
                 for (int r = 0; r < m->pd; ++r) {
-                    double acc = bd[r];
+                    double acc = bd[r], wsum = 0.0;
                     for (int k = 0; k < D; ++k) {
                         wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
                         acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
+                        wsum += (double)wg[(size_t)r * D + k];
                     }
                     dc[r] = (float)acc;
+                    dc[m->pd + r] = (float)wsum;
                 }
                 o.wg = put_f32(wg.data(), wg.size()); o.dc = put_f32(dc.data(), dc.size());
             }

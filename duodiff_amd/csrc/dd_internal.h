@@ -278,11 +278,19 @@ hipError_t launch_final(const FinalArgs& a, hipStream_t s);
 struct HeadDecArgs {
     const float* x;    // [Mp, D] fp32 residual stream
     const float* wg;   // [pd, D]
-    const float* c;    // [pd]
+    const float* c;    // [2 pd]: c, then the row sums of wg (the kernel multiplies the un-normalised rows: rowops.hip)
     float* dec;        // [Mp, pd]
     int M, pd;
     int tok_l, tok_e;  // > 0: rows are images of tok_l tokens whose first tok_e (the extra tokens) are NOT decoded; 0: every row
+    // early-exit MLP probe folded into the launch (srow != null; D = 256 / 512): srow[row] = sigmoid(x[row,:] . w + b) for EVERY row (the extra
+    // tokens' too), w = pw_base + pi D, b = pb_base[pi], pi = st->t_final * t_mul + add (launch_ee_probe's row selection)
+    float* srow = nullptr;
+    const float* pw_base = nullptr;
+    const float* pb_base = nullptr;
+    const StepState* st = nullptr;
+    int t_mul = 0, add = 0;
 };
+bool head_dec_probe_supported(int D);
 bool head_dec_supported(int D, int pd);
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s);
 

@@ -572,13 +572,18 @@ __global__ void __launch_bounds__(256) final_kernel(const FinalArgs a) {
 
 // Tiled variant of final_kernel: a workgroup owns a 16x16 pixel tile of one image and first parks the
 // 18x18xC halo of the unpatchified decoder output in LDS, so every decoder value is fetched once
-// instead of up to nine times.  Same arithmetic, same rounding order.
+// instead of up to nine times.  Same arithmetic, same rounding order (a tap outside the image multiplies a zero of the halo instead of
+// being skipped: fmaf(w, 0, acc) == acc).
+// CT = the channel count at compile time (3, 4; 0: a.C at run time): with it the 9 C^2 conv weights are unconditional scalar loads, one
+// output channel's 9 C at a time, PT = the patch size likewise (the halo gather divides by it) -- the run-time form tested co < C / ci < C around every one of 144 candidate loads (221 scalar branches,
+// 151 s_load_dword, the weights' SGPRs spilled to VGPR lanes: ~3 900 instructions for a kernel every sampling step waits for).
+template <int CT, int PT>
 __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
 #pragma clang fp contract(off)
     // (row pitch 48 = 16 mod 32 words: the two 16-pixel rows a 32-lane group reads fall into disjoint bank halves; pitch 19 gave every tap read
     // a 2-way conflict on three banks -- 1.7 conflict cycles per LDS-active cycle in the round 2-4 profiles, for a kernel that is latency, not LDS)
     __shared__ float u[4][18][48];
-    const int S = a.S, P = a.P, C = a.C, g = S / P, pd = P * P * C;
+    const int S = a.S, P = PT ? PT : a.P, C = CT ? CT : a.C, g = S / P, pd = P * P * C;
     const int tiles = (S + 15) / 16;
     const int b = blockIdx.x / (tiles * tiles), ty = (blockIdx.x / tiles) % tiles, tx = blockIdx.x % tiles;
     const int tid = threadIdx.x;
@@ -604,18 +609,9 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
             }
         }
     }
-    float wc[4][4][9], bc[4];
     const int layer = a.layer_B > 0 ? b / a.layer_B : 0;      // (early-exit heads batched into one launch: this image's layer)
     const float* wconv = a.wconv + layer * a.w_stride;
     const float* bconv = a.bconv + layer * a.b_stride;
-#pragma unroll
-    for (int co = 0; co < 4; ++co) {
-        bc[co] = co < C ? bconv[co] : 0.f;
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wc[co][ci][k] = (co < C && ci < C) ? wconv[(co * C + ci) * 9 + k] : 0.f;
-    }
     for (int idx = tid; idx < 18 * 18; idx += 256) {
         const int hy = idx / 18, hx = idx % 18;
         const int yy = ty * 16 + hy - 1, xx = tx * 16 + hx - 1;
@@ -634,25 +630,27 @@ __global__ void __launch_bounds__(256) final_tiled_kernel(const FinalArgs a) {
         a.st->t_model = table ? t_next : (float)tn;
     }
     if (!inside) return;
-    float acc[4];
+    constexpr int CM = CT ? CT : 4;
+    float uu[CM][9];
 #pragma unroll
-    for (int co = 0; co < 4; ++co) acc[co] = bc[co];
+    for (int ci = 0; ci < CM; ++ci)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+        for (int k = 0; k < 9; ++k) uu[ci][k] = ci < C ? u[ci][ly + k / 3][lx + k % 3] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int yy = y + dy - 1, xx = x + dx - 1;
-            if (yy < 0 || yy >= S || xx < 0 || xx >= S) continue;   // same skipped taps as the untiled kernel
+    for (int co = 0; co < CM; ++co) {
+        if (co < C) {
+            // uniform address, constant address space: scalar loads (s_load_dwordx8 ...), one output channel's 9 C weights live at a time
+            const __attribute__((address_space(4))) float* wp = (const __attribute__((address_space(4))) float*)(wconv + co * C * 9);
+            float v = bconv[co];
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                if (ci < C) {
-                    const float uv = u[ci][ly + dy][lx + dx];
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-                    for (int co = 0; co < 4; ++co)
-                        if (co < C) acc[co] = fmaf(wc[co][ci][dy * 3 + dx], uv, acc[co]);
-                }
-            }
+                for (int ci = 0; ci < CM; ++ci)
+                    if (ci < C) v = fmaf(wp[ci * 9 + k], uu[ci][k], v);
+            acc[co] = v;
         }
+    }
     const float sigma = a.variance == 1 ? cf.sigma_beta : cf.sigma_tilde;
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
@@ -978,54 +976,152 @@ template hipError_t launch_layernorm<float>(const float*, const float*, const fl
 // ------------------------------------------------------------------------------------------
 // Output head, first half (reference models/uvit.py:377-378): dec = decoder_pred(norm(x)) in one launch, exact fp32
 // (v_mfma_f32_16x16x4_f32 == an fmaf chain), so eps never sees a bf16 rounding and the normalised rows never exist in HBM.
-// The host folds the affine part of the LayerNorm into the Linear once (finalize):
-//     dec[m] = sum_k (W[m,k] gamma[k]) * ((x[k] - mean) rstd)  +  (b[m] + sum_k W[m,k] beta[k])  =  Wg . xn + c
-// Workgroup = 128 rows, wave = 16 rows held in registers in MFMA B-operand order (lane: row l & 15, k-quad l >> 4),
-// two-pass statistics as layernorm_kernel; Wg is parked in LDS in A-operand order once per workgroup.
+// The host folds the affine part of the LayerNorm into the Linear once (finalize), and the kernel the normalisation itself
+// out of the product, so that the MFMAs run on the rows AS THEY ARRIVE instead of behind the last load and the statistics:
+//     dec[m] = sum_k (W[m,k] gamma[k]) (x[k] - mean) rstd + (b[m] + sum_k W[m,k] beta[k])
+//            = rstd * ( Wg[m,:] . d  -  mean_d * wsum[m] )  +  c[m],        d = x - x[0],  mean_d = mean(d),  wsum[m] = sum_k Wg[m,k]
+// (the shift by the row's own first element keeps |mean_d| within the row's spread whatever offset the row carries, so the
+// subtraction loses nothing a LayerNorm of the same row would keep; rstd from the two-pass variance of d, as layernorm_kernel).
+// Workgroup = 128 rows, wave = 16 rows held in registers in MFMA B-operand order (lane: row l & 15, k-quad l >> 4);
+// Wg is parked in LDS in A-operand order once per workgroup.  A wave's row loads are all in flight before it waits for its
+// share of Wg; the MFMAs of k-block j wait for load j only (counted vmcnt), the statistics follow on the registers.
 // HBM: the fp32 rows once (the launch's roof), dec once.
 // ------------------------------------------------------------------------------------------
+// 16-byte global load the compiler does not count, and the wait that makes its destination usable ("+v": every use is ordered behind it)
+// HAND = false: an ordinary load / nothing -- hipcc counts and waits itself (D >= 768: the row quads + the Wg share are more than the 63 operations
+// the counter holds, and more registers than the 256 VGPRs a wave has: hipcc parks quads in AGPRs, which must not happen to a register whose load
+// is still in flight)
+template <int OFF, bool HAND>
+__device__ __forceinline__ void asm_load_quad(f32x4& dst, const float* p) {
+    if constexpr (HAND) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "i"(OFF));
+    else dst = *reinterpret_cast<const f32x4*>(p + OFF / 4);
+}
+template <int N, bool HAND>
+__device__ __forceinline__ void landed_at_vmcnt(f32x4& v) {
+    static_assert(!HAND || N < 64, "a 6-bit counter");
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
 // NW waves per workgroup: 8 (two per SIMD: D <= 512, D / 4 row registers per lane), 4 at D = 768 / 1024 (192 / 256 row registers: one wave per SIMD).
-template <int D, int NT, int NW = 8>
+// PROBE (early-exit heads, reference models/early_exit.py:31-37): the launch also writes the MLP probe's per-token value
+//     srow[row] = sigmoid(x[row,:] . w + b)        (w, b: probe row t * t_mul + add, t read from the step state as in ee_probe_rows_kernel)
+// for the rows it decodes -- the quads are in registers anyway: 4 VALU fmas per quad under the MFMAs instead of a second pass over the
+// rows in HBM (13 launches per step) -- and, patch-rows-only launches, for the extra-token rows in a short pass of their own behind the units.
+template <int D, int NT, int NW = 8, bool PROBE = false>
 __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) {
     constexpr int J = D / 16;
+    constexpr bool HAND = J + J * NT / NW + (PROBE ? 1 : 0) <= 52;     // D <= 512: J row quads + the Wg share <= 63 operations in flight, all of them in VGPRs (<= 208 of 256)
     extern __shared__ __attribute__((aligned(16))) char head_lds[];
     f32x4* wl = reinterpret_cast<f32x4*>(head_lds);                 // [J][NT][64]
+    f32x4* pwl = wl + J * NT * 64;                                  // PROBE: [D / 4] the probe row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
-    // Wg fragments of this wave (L2-resident) -> LDS in A-operand order, all loads in flight at once
-    constexpr int WI = J * NT / NW;
-    static_assert(J * NT % NW == 0, "one equal share of Wg fragments per wave");
-    {
-        f32x4 wv[WI];
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int item = wave + NW * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
-            wv[i] = *reinterpret_cast<const f32x4*>(a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q);
-            if (m >= a.pd) wv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wl[(wave + NW * i) * 64 + lane] = wv[i];
-    }
-    f32x4 c4[NT];    // lane holds dec[row][16 ct + 4 q + i], i < 4 (pd % 4 == 0: a quad is inside or outside)
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) c4[ct] = *reinterpret_cast<const f32x4*>(a.c + (16 * ct + 4 * q < a.pd ? 16 * ct + 4 * q : 0));
-    __syncthreads();
+    static_assert(!PROBE || (D % 256 == 0 && D / 256 <= NW), "the probe row is staged by D / 256 waves");
+    int pi = 0;
+    if constexpr (PROBE) pi = (a.t_mul ? a.st->t_final * a.t_mul : 0) + a.add;
     // 16-row units dealt to the waves of the whole grid, unit u -> wave (u / grid) % NW of workgroup u % grid: with
     // M = B (256 + extras) rows the few units beyond one per wave land on different CUs (128-row tiles per workgroup
-    // left one workgroup for a second round of the whole launch).  Nothing below synchronises across waves.
+    // left one workgroup for a second round of the whole launch).  Nothing below the barrier synchronises across waves.
     // tok_l > 0: only the patch rows (tokens l >= tok_e of every tok_l-row image; 16 | tok_l - tok_e) are decoded -- the extra tokens'
     // rows of dec are never read (unpatchify takes the patch tokens, reference models/uvit.py:379-381) and at B = 128 those 128 rows
     // were 8 units more than one per wave: a second round of the whole launch on 8 CUs
     const int upi = a.tok_l > 0 ? (a.tok_l - a.tok_e) / 16 : 0;                       // units per image
     const int units = a.tok_l > 0 ? (a.M / a.tok_l) * upi : (a.M + 15) / 16, stride = NW * (int)gridDim.x;
-    for (int u = wave * (int)gridDim.x + (int)blockIdx.x; u < units; u += stride) {
-        const long long row = a.tok_l > 0 ? (long long)(u / upi) * a.tok_l + a.tok_e + (u % upi) * 16 + n : (long long)u * 16 + n;
-        const bool ok = row < a.M;
-        const f32x4* wlp = wl + lane;
-        asm volatile("" : "+v"(wlp));   // opaque per unit: the LDS fragment reads are loop-invariant and hipcc would hoist all of them (spills)
-        const float* xr = a.x + (ok ? row : (long long)a.M - 1) * D + 4 * q;
-        f32x4 xv[J];
+    auto row_of = [&](int u) -> long long {
+        return a.tok_l > 0 ? (long long)(u / upi) * a.tok_l + a.tok_e + (u % upi) * 16 + n : (long long)u * 16 + n;
+    };
+    // The row quads and the Wg fragments travel as asm loads: hipcc does not count those, so every wait below is written by hand
+    // (vector memory returns in order: "at most N outstanding" = everything but the youngest N has landed; loads the compiler
+    // issues in between only make a hand-written wait stricter).  A compiler-counted version waited for ALL row loads in front
+    // of the first MFMA (its counters merge conservatively around the unit loop).
+    f32x4 xv[J];
+    auto request = [&](int u) {     // this lane's quads of its row of unit u (rows past M: the last row, never stored)
+        const long long row = row_of(u);
+        const float* xr = a.x + (row < a.M ? row : (long long)a.M - 1) * D + 4 * q;
+        [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+            (asm_load_quad<64 * JJ, HAND>(xv[JJ], xr), ...);
+        }(std::make_integer_sequence<int, J>{});
+    };
+    // Wg fragments of this wave (L2-resident) -> LDS in A-operand order; requested FIRST, the first unit's rows right behind
+    // them: the rows are in flight while the workgroup parks Wg and meets at the barrier
+    constexpr int WI = J * NT / NW;
+    static_assert(J * NT % NW == 0, "one equal share of Wg fragments per wave");
+    static_assert(64 * (J - 1) < 4096, "the row quads' immediate offsets");
+    static_assert(!HAND || J + WI <= 63, "the vector-memory counter holds 63 operations");
+    int u = wave * (int)gridDim.x + (int)blockIdx.x;
+    {
+        f32x4 wv[WI];
 #pragma unroll
-        for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xr + 16 * j);
+        for (int i = 0; i < WI; ++i) {
+            const int item = wave + NW * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
+            const float* wp = a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q;   // (rows m >= pd feed output columns that are never stored)
+            asm_load_quad<0, HAND>(wv[i], wp);
+        }
+        // (every wave requests a quad of the probe row, D / 256 of them park theirs: an asm load under a branch hands hipcc a phi
+        // to copy -- out of a register whose load is still in flight)
+        f32x4 pwq;
+        if constexpr (PROBE) asm_load_quad<0, HAND>(pwq, a.pw_base + (long long)pi * D + (wave % (D / 256)) * 256 + lane * 4);
+        if (u < units) request(u);
+        else if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wave without a unit: nothing younger than its fragments)
+        [&]<int... II>(std::integer_sequence<int, II...>) {                     // the fragments have landed when at most the J row loads are outstanding
+            (landed_at_vmcnt<J, HAND>(wv[II]), ...);
+        }(std::make_integer_sequence<int, WI>{});
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wl[(wave + NW * i) * 64 + lane] = wv[i];
+        if constexpr (PROBE) {
+            landed_at_vmcnt<J, HAND>(pwq);            // (requested in front of the row quads)
+            if (wave < D / 256) pwl[wave * 64 + lane] = pwq;
+        }
+    }
+    __syncthreads();
+    while (u < units) {
+        const long long row = row_of(u);
+        const bool ok = row < a.M;
+        typedef const __attribute__((address_space(3))) f32x4* lds_quad_ptr;   // (kept in the LDS address space: behind the opaque asm a generic
+        lds_quad_ptr wlp = (lds_quad_ptr)wl + lane;                           //  pointer turns every fragment read into a flat load, which counts in vmcnt too)
+        asm volatile("" : "+v"(wlp));   // opaque per unit: the LDS fragment reads are loop-invariant and hipcc would hoist all of them (spills)
+        // the shift: the row's first element (held by the lane of k-quad 0)
+        landed_at_vmcnt<J - 1, HAND>(xv[0]);
+        const float x0 = __shfl(xv[0][0], n);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lds_quad_ptr pwp = (lds_quad_ptr)pwl + q;
+        asm volatile("" : "+v"(pwp));
+        f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+        [&]<int... JJ>(std::integer_sequence<int, JJ...>) {      // fully unrolled: xv[] must stay in registers
+            ([&] {
+                constexpr int j = JJ;
+                landed_at_vmcnt<J - 1 - j, HAND>(xv[j]);      // quad j has landed
+                if constexpr (PROBE) {
+                    const f32x4 pw4 = pwp[4 * j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pacc[e] = fmaf(xv[j][e], pw4[e], pacc[e]);
+                    asm volatile("" : "+v"(pacc));      // (here, not after the loop: hipcc parked every quad and probe weight in scratch to run the 128 fmas at the end)
+                }
+                xv[j] = xv[j] - x0;
+                f32x4 w[NT];
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) w[ct] = wlp[(j * NT + ct) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][e], xv[j][e], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);     // (hipcc would sink this block's MFMAs below the later waits)
+            }(), ...);
+        }(std::make_integer_sequence<int, J>{});
+        // c and wsum of this lane's output columns are fetched HERE, per unit, through a pointer hipcc cannot see through: loaded in
+        // front of the unit loop they are compiler-counted loads older than the row quads -- hipcc waited for them (vmcnt(0), i.e. for
+        // every row quad) before the first MFMA
+        const float* cw = a.c;
+        asm volatile("" : "+s"(cw));
+        f32x4 c4[NT], ws4[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const int col = 16 * ct + 4 * q < a.pd ? 16 * ct + 4 * q : 0;
+            c4[ct] = *reinterpret_cast<const f32x4*>(cw + col);
+            ws4[ct] = *reinterpret_cast<const f32x4*>(cw + a.pd + col);
+        }
+        // statistics of d on the registers (two passes), under the other wave's MFMAs
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < J; ++j) s4 += xv[j];
@@ -1043,26 +1139,46 @@ __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) 
         sq += __shfl_xor(sq, 16);
         sq += __shfl_xor(sq, 32);
         const float rstd = 1.0f / sqrtf(sq / (float)D + 1e-5f);
+        // (used here, outside the branch: a wait for c / wsum that exists on the storing path only leaves them "in flight" on the other
+        // one, and hipcc then waits vmcnt(0) -- for every row quad -- where the next unit first overwrites their registers)
 #pragma unroll
-        for (int j = 0; j < J; ++j) xv[j] = (xv[j] - mean) * rstd;
-        f32x4 acc[NT];
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < J; ++j) {      // fully unrolled: xv[] must stay in registers
-            f32x4 w[NT];
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) w[ct] = wlp[(j * NT + ct) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][e], xv[j][e], acc[ct], 0, 0, 0);
-        }
-        if (ok) {
+        for (int ct = 0; ct < NT; ++ct) asm volatile("" : "+v"(c4[ct]), "+v"(ws4[ct]));
+        if (ok) {      // lane holds dec[row][16 ct + 4 q + i], i < 4 (pd % 4 == 0: a quad is inside or outside)
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const int col = 16 * ct + 4 * q;
-                if (col < a.pd) *reinterpret_cast<f32x4*>(a.dec + row * a.pd + col) = acc[ct] + c4[ct];
+                if (col < a.pd) *reinterpret_cast<f32x4*>(a.dec + row * a.pd + col) = (acc[ct] - mean * ws4[ct]) * rstd + c4[ct];
+            }
+        }
+        if constexpr (PROBE) {
+            float pd = (pacc[0] + pacc[1]) + (pacc[2] + pacc[3]);
+            pd += __shfl_xor(pd, 16);
+            pd += __shfl_xor(pd, 32);
+            if (ok && q == 0) a.srow[row] = 1.0f / (1.0f + expf(-(pd + a.pb_base[pi])));
+        }
+        const int un = u + stride;
+        if (un < units) request(un);
+        u = un;
+    }
+    if constexpr (PROBE) {
+        // patch-rows-only launch: the probe's values for the extra-token rows (tok_e per image), 16 rows per wave 0 of the first workgroups
+        if (a.tok_l > 0 && a.tok_e > 0 && wave == 0) {
+            const int nex = (a.M / a.tok_l) * a.tok_e;
+            for (int eu = (int)blockIdx.x; eu * 16 < nex; eu += (int)gridDim.x) {
+                const int idx = eu * 16 + n, ii = idx < nex ? idx : nex - 1;
+                const long long row = (long long)(ii / a.tok_e) * a.tok_l + ii % a.tok_e;
+                const float* xr = a.x + row * D + 4 * q;
+                f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int j = 0; j < J; ++j) {
+                    const f32x4 xq = *reinterpret_cast<const f32x4*>(xr + 16 * j), pw4 = pwl[4 * j + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pacc[e] = fmaf(xq[e], pw4[e], pacc[e]);
+                }
+                float pd = (pacc[0] + pacc[1]) + (pacc[2] + pacc[3]);
+                pd += __shfl_xor(pd, 16);
+                pd += __shfl_xor(pd, 32);
+                if (idx < nex && q == 0) a.srow[row] = 1.0f / (1.0f + expf(-(pd + a.pb_base[pi])));
             }
         }
     }
@@ -1074,14 +1190,21 @@ bool head_dec_supported(int D, int pd) {
     return D == 256 || D == 512 || (D == 768 && nt <= 3) || (D == 1024 && nt <= 2);     // (D / 16) nt KB of LDS for Wg
 }
 
+bool head_dec_probe_supported(int D) { return D == 256 || D == 512; }
+
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s) {
     if (!head_dec_supported(D, a.pd) || a.M < 1) return hipErrorInvalidValue;
     if (a.tok_l > 0 && (a.tok_e < 0 || a.tok_e >= a.tok_l || (a.tok_l - a.tok_e) % 16 || a.M % a.tok_l)) return hipErrorInvalidValue;
+    if (a.srow && (!head_dec_probe_supported(D) || !a.pw_base || !a.pb_base || (a.t_mul && !a.st))) return hipErrorInvalidValue;
     const int nt = (a.pd + 15) / 16;
     const int wgs = (a.M + 127) / 128;
     const dim3 grid((unsigned)(wgs < num_cus ? wgs : num_cus));     // one workgroup per CU (LDS), 16-row units dealt inside
-    const size_t lds = (size_t)(D / 16) * nt * 1024;
-#define DD_HEAD(DV, NV) hipLaunchKernelGGL((head_dec_kernel<DV, NV>), grid, dim3(512), lds, s, a)
+    const size_t lds = (size_t)(D / 16) * nt * 1024 + (a.srow ? (size_t)D * 4 : 0);
+#define DD_HEAD(DV, NV)                                                                                  \
+    do {                                                                                                 \
+        if (a.srow) hipLaunchKernelGGL((head_dec_kernel<DV, NV, 8, true>), grid, dim3(512), lds, s, a);  \
+        else hipLaunchKernelGGL((head_dec_kernel<DV, NV>), grid, dim3(512), lds, s, a);                  \
+    } while (0)
     if (D == 1024) {
         if (nt == 1) hipLaunchKernelGGL((head_dec_kernel<1024, 1, 4>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((head_dec_kernel<1024, 2, 4>), grid, dim3(256), lds, s, a);
@@ -1100,7 +1223,9 @@ hipError_t init_rowops_kernels() {
     hipError_t e = hipSuccess;
 #define DD_HEAD_ATTR(DV, NV)                                                                                       \
     if (e == hipSuccess)                                                                                           \
-        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024);
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024); \
+    if (e == hipSuccess)                                                                                           \
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024 + DV * 4);
     DD_HEAD_ATTR(512, 1) DD_HEAD_ATTR(512, 2) DD_HEAD_ATTR(512, 3) DD_HEAD_ATTR(512, 4)
     DD_HEAD_ATTR(256, 1) DD_HEAD_ATTR(256, 2) DD_HEAD_ATTR(256, 3) DD_HEAD_ATTR(256, 4)
 #undef DD_HEAD_ATTR
@@ -1138,7 +1263,11 @@ template hipError_t launch_fill_random<float>(float*, long long, unsigned, float
 hipError_t launch_final(const FinalArgs& a, hipStream_t s) {
     if (a.S >= 16) {
         const int tiles = (a.S + 15) / 16;
-        hipLaunchKernelGGL(final_tiled_kernel, dim3(a.B * tiles * tiles), dim3(256), 0, s, a);
+        const dim3 grid(a.B * tiles * tiles);
+        if (a.C == 3 && a.P == 4) hipLaunchKernelGGL((final_tiled_kernel<3, 4>), grid, dim3(256), 0, s, a);          // CelebA-64, CIFAR-10
+        else if (a.C == 3 && a.P == 2) hipLaunchKernelGGL((final_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a);     // ImageNet-64
+        else if (a.C == 4 && a.P == 2) hipLaunchKernelGGL((final_tiled_kernel<4, 2>), grid, dim3(256), 0, s, a);     // latent 32 x 32 x 4
+        else hipLaunchKernelGGL((final_tiled_kernel<0, 0>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const long long npix = (long long)a.B * a.S * a.S;
