@@ -92,6 +92,7 @@ SIGNATURES = {
     "dd_dev_qkv_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),
+    "dd_dev_head_dec": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_poison_workspaces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
     "dd_dev_last_sample_chains": (C.c_int, [C.c_void_p]),

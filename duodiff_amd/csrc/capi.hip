@@ -77,6 +77,23 @@ struct BlockW {
     const char* rls_img = nullptr;  // skip_linear weight [D, 2 D], ditto (out-blocks)
 };
 
+// head_dec_kernel operands from a head's LayerNorm (gamma, beta) and decoder_pred (W [pd, D], b): wg = W diag(gamma); dc = c [pd] = b + W . beta,
+// then the row sums of wg [pd] (the kernel multiplies the un-normalised rows: dec = rstd (wg . d - mean_d wsum) + c, rowops.hip)
+static void fold_head_norm(int D, int pd, const float* wd, const float* bd, const float* ng, const float* nb, std::vector<float>& wg, std::vector<float>& dc) {
+    wg.assign((size_t)pd * D, 0.f);
+    dc.assign(2 * (size_t)pd, 0.f);
+    for (int r = 0; r < pd; ++r) {
+        double acc = bd[r], wsum = 0.0;
+        for (int k = 0; k < D; ++k) {
+            wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
+            acc += (double)wd[(size_t)r * D + k] * (double)nb[k];
+            wsum += (double)wg[(size_t)r * D + k];
+        }
+        dc[r] = (float)acc;
+        dc[pd + r] = (float)wsum;
+    }
+}
+
 struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred; dc = c [pd], row sums of wg [pd]) or null
 
 struct GraphKey {
@@ -1221,17 +1238,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     size_t o_wg = 0, o_dc = 0;
     if (fused_head) {
         const std::vector<float>&wd = P("decoder_pred.weight"), &bd = P("decoder_pred.bias"), &ng = P("norm.weight"), &nbv = P("norm.bias");
-        std::vector<float> wg((size_t)m->pd * D), dc(2 * (size_t)m->pd);     // dc = c [pd], then the row sums of wg [pd]
-        for (int r = 0; r < m->pd; ++r) {
-            double acc = bd[r], wsum = 0.0;
-            for (int k = 0; k < D; ++k) {
-                wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
-                acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
-                wsum += (double)wg[(size_t)r * D + k];
-            }
-            dc[r] = (float)acc;
-            dc[m->pd + r] = (float)wsum;
-        }
+        std::vector<float> wg, dc;
+        fold_head_norm(D, m->pd, wd.data(), bd.data(), ng.data(), nbv.data(), wg, dc);
         o_wg = put_f32(wg.data(), wg.size()); o_dc = put_f32(dc.data(), dc.size());
     }
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
@@ -1252,17 +1260,8 @@ int dd_model_finalize(dd_model* m, int precision) {
             o.bconv = put_f32(P(p + "final_layer.bias").data(), m->cfg.in_chans);
             if (fused_head) {   // as the final head: dec = (W . diag(gamma)) xn + (b + W . beta)
                 const std::vector<float>&wd = P(p + "decoder_pred.weight"), &bd = P(p + "decoder_pred.bias"), &ng = P(p + "norm.weight"), &nbv = P(p + "norm.bias");
-                std::vector<float> wg((size_t)m->pd * D), dc(2 * (size_t)m->pd);
-                for (int r = 0; r < m->pd; ++r) {
-                    double acc = bd[r], wsum = 0.0;
-                    for (int k = 0; k < D; ++k) {
-                        wg[(size_t)r * D + k] = wd[(size_t)r * D + k] * ng[k];
-                        acc += (double)wd[(size_t)r * D + k] * (double)nbv[k];
-                        wsum += (double)wg[(size_t)r * D + k];
-                    }
-                    dc[r] = (float)acc;
-                    dc[m->pd + r] = (float)wsum;
-                }
+                std::vector<float> wg, dc;
+                fold_head_norm(D, m->pd, wd.data(), bd.data(), ng.data(), nbv.data(), wg, dc);
                 o.wg = put_f32(wg.data(), wg.size()); o.dc = put_f32(dc.data(), dc.size());
             }
             hoffs.push_back(o);
@@ -1678,8 +1677,10 @@ static int enqueue_ee_step(dd_ctx* c, dd_model* m, float* ws, float* x, const in
     FinalArgs fa{m->dec, m->wconv, m->bconv, nullptr, nullptr, eps, nullptr, c->st, c->coef,
                  B, m->cfg.in_chans, m->cfg.img_size, m->cfg.patch_size, m->L, m->extras, DD_NOISE_NONE, 0, 0};
     DD_HIP(c, launch_final(fa, s));
-    DD_HIP(c, launch_ee_select(outs, eps, cls, thr, depth, B, chw, mo, idx_tab, err_tab, c->st, s, B_all > 0 ? B_all : B, b0, sums));
-    DD_HIP(c, launch_ddpm_step_state(x, mo, c->st, c->coef, B, m->cfg.in_chans, m->cfg.img_size, noise_mode, 1, s, b0));
+    // exit layer per image, the selected output and the DDPM update in one launch (dd_early_exit_select + the step kernel, fused: same arithmetic)
+    DD_HIP(c, launch_ee_select_step(x, outs, eps, cls, thr, depth, idx_tab, err_tab, B_all > 0 ? B_all : B, b0, sums, c->st, c->coef, B,
+                                    m->cfg.in_chans, m->cfg.img_size, noise_mode, 1, s));
+    (void)mo;
     return DD_OK;
 }
 
@@ -2053,6 +2054,53 @@ int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float
         DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
         DD_TRY(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) DD_TRY(launch_qkv_attention((const bf16_t*)dH, (const bf16_t*)dW, (const float*)dB, (const bf16_t*)dQ, nullptr, nullptr, nullptr, (bf16_t*)dO, B, L, H, D, extras, s));
+        DD_TRY(hipEventRecord(e1, s));
+        DD_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DD_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *ms_out = ms / (float)iters;
+    }
+#undef DD_TRY
+    cleanup();
+    return DD_OK;
+}
+
+int dd_dev_head_dec(dd_ctx* c, int M, int D, int pd, int tok_l, int tok_e, const float* x_host, const float* norm_g, const float* norm_b,
+                    const float* wdec, const float* bdec, float* dec_host, const float* probe_w, const float* probe_b, float* srow_host,
+                    int iters, void* stream, float* ms_out) {
+    if (!c || !x_host || !norm_g || !norm_b || !wdec || !bdec || !dec_host || M < 1 || iters < 0) return DD_ERR_INVALID;
+    if (!head_dec_supported(D, pd)) return fail(c, DD_ERR_UNSUPPORTED, "head_dec: D in {256, 512, 768, 1024}, pd % 4 == 0, pd <= 64");
+    const bool probe = probe_w && probe_b && srow_host;
+    if (probe && !head_dec_probe_supported(D)) return fail(c, DD_ERR_UNSUPPORTED, "head_dec with the probe: D in {256, 512}");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> wg, dc;
+    fold_head_norm(D, pd, wdec, bdec, norm_g, norm_b, wg, dc);
+    void *dX = nullptr, *dW = nullptr, *dC = nullptr, *dO = nullptr, *dP = nullptr, *dPb = nullptr, *dS = nullptr;
+    auto cleanup = [&]() { for (void* p : {dX, dW, dC, dO, dP, dPb, dS}) if (p) (void)hipFree(p); };
+#define DD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(c, DD_ERR_HIP, hipGetErrorString(e_)); } } while (0)
+    DD_TRY(hipMalloc(&dX, (size_t)M * D * 4)); DD_TRY(hipMalloc(&dW, wg.size() * 4)); DD_TRY(hipMalloc(&dC, dc.size() * 4)); DD_TRY(hipMalloc(&dO, (size_t)M * pd * 4));
+    DD_TRY(hipMemcpy(dX, x_host, (size_t)M * D * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dW, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemcpy(dC, dc.data(), dc.size() * 4, hipMemcpyHostToDevice));
+    DD_TRY(hipMemset(dO, 0xFF, (size_t)M * pd * 4));      // NaN: rows the launch does not decode stay recognisable
+    HeadDecArgs ha{(const float*)dX, (const float*)dW, (const float*)dC, (float*)dO, M, pd, tok_l, tok_e};
+    if (probe) {
+        DD_TRY(hipMalloc(&dP, (size_t)D * 4)); DD_TRY(hipMalloc(&dPb, 4)); DD_TRY(hipMalloc(&dS, (size_t)M * 4));
+        DD_TRY(hipMemcpy(dP, probe_w, (size_t)D * 4, hipMemcpyHostToDevice));
+        DD_TRY(hipMemcpy(dPb, probe_b, 4, hipMemcpyHostToDevice));
+        DD_TRY(hipMemset(dS, 0xFF, (size_t)M * 4));
+        ha.srow = (float*)dS; ha.pw_base = (const float*)dP; ha.pb_base = (const float*)dPb;     // (probe row 0: t_mul = add = 0, the step state is not read)
+    }
+    DD_TRY(launch_head_dec(ha, D, c->num_cus, s));
+    DD_TRY(hipStreamSynchronize(s));
+    DD_TRY(hipMemcpy(dec_host, dO, (size_t)M * pd * 4, hipMemcpyDeviceToHost));
+    if (probe) DD_TRY(hipMemcpy(srow_host, dS, (size_t)M * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && ms_out) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        DD_TRY(hipEventCreate(&e0)); DD_TRY(hipEventCreate(&e1));
+        DD_TRY(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) DD_TRY(launch_head_dec(ha, D, c->num_cus, s));
         DD_TRY(hipEventRecord(e1, s));
         DD_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

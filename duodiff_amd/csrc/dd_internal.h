@@ -321,6 +321,10 @@ hipError_t launch_ee_probe_reduce(const float* srow, float* out, int rows, int L
 // column idx_col0 on; sums: err_mean receives the plain per-layer SUM over the chain's images (launch_ee_mean_combine joins the chains)
 hipError_t launch_ee_select(const float* outs, const float* eps, const float* cls, float thr, int depth, int B, long long chw,
                             float* mo, int* idx, float* err_mean, const StepState* st, hipStream_t s, int idx_stride = 0, int idx_col0 = 0, bool sums = false);
+// launch_ee_select + launch_ddpm_step_state in one launch (the device-resident loop; idx_col0 = the chain's first image within the whole batch)
+hipError_t launch_ee_select_step(float* x, const float* outs, const float* eps, const float* cls, float thr, int depth, int* idx, float* err_mean,
+                                 int idx_stride, int idx_col0, bool sums, StepState* st, const StepCoef* coef, int B, int C, int S,
+                                 int noise_mode, int advance, hipStream_t s);
 hipError_t launch_ee_mean_combine(const float* s0, const float* s1, float* err, int depth, int t_lo, int t_hi, int B, hipStream_t s);
 // b0: index of the launch's first image within the whole batch (only the Philox pixel ids depend on it)
 hipError_t launch_ddpm_step_state(float* x, const float* eps, StepState* st, const StepCoef* coef, int B, int C, int S,

@@ -712,6 +712,37 @@ __global__ void __launch_bounds__(256) ddpm_step_state_kernel(float* __restrict_
     }
 }
 
+// ee_select_kernel and the update above in one launch (the device-resident early-exit loop: two launches less on every step's serial tail,
+// and the selected model output never travels through HBM): per pixel, the image's exit layer from cls (ee_select_kernel's rule), then the
+// update on (outputs ++ [eps])[idx] -- the same operations in the same order as the two kernels.
+__global__ void __launch_bounds__(256) ee_select_step_kernel(float* __restrict__ x, const float* __restrict__ outs, const float* __restrict__ eps,
+                                                             const float* __restrict__ cls, float thr, int depth, int* __restrict__ idx_out,
+                                                             int idx_stride, int idx_col0, StepState* st, const StepCoef* __restrict__ coef,
+                                                             int B, int C, int S, int noise_mode, int advance, long long pix0) {
+#pragma clang fp contract(off)
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long hw = (long long)S * S;
+    const int t = st->t_final;
+    if (advance && pix == 0) { st->t = t - 1; st->t_model = (float)(t - 1); }   // no block of this kernel reads t / t_model
+    if (pix >= (long long)B * hw) return;
+    const StepCoef cf = coef[t < 0 ? 0 : (t > 999 ? 999 : t)];
+    f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0 && noise_mode == 2) zn = philox_normal4(st->seed, (unsigned long long)(pix + pix0), t);
+    const long long b = pix / hw, p = pix - b * hw;
+    int idx = -1;
+    for (int k = 0; k < depth && idx < 0; ++k)
+        if (cls[(long long)k * B + b] <= thr) idx = k;
+    if (idx < 0) idx = (0.0f <= thr) ? depth : 0;
+    if (idx_out && p == 0) idx_out[(long long)t * idx_stride + idx_col0 + b] = idx;     // row t of indices_by_timestep (eesampler.py:71)
+    const float* src = idx == depth ? eps : outs + (long long)idx * B * C * hw;
+    for (int c = 0; c < C; ++c) {
+        const long long e = (b * C + c) * hw + p;
+        float v = cf.c1 * (x[e] - cf.c2 * src[e]);
+        if (t > 0 && noise_mode == 2) v = v + cf.sigma_tilde * zn[c];
+        x[e] = v;
+    }
+}
+
 // out = a*x + b*m + c*z, each product rounded (no FMA contraction): the common form of the reference's
 // predict_original / predict_previous post-processing (sampler.py:59-79) and of a DDIM step (:112-120).
 __global__ void affine_step_kernel(const float* __restrict__ x, const float* __restrict__ m,
@@ -762,7 +793,7 @@ __global__ void __launch_bounds__(256) to_images_kernel(const float* __restrict_
 // image's 257 rows on four waves one after the other (164 us per layer at B = 128: 62 % of the early-exit loop's overhead):
 //   rows:   grid (B, slices): each wave takes rows of its slice, two in flight; row value s_l = sigmoid(w . x_l + b) with the per-lane
 //           fma chain over k = lane, lane + 64, ... and the xor-shuffle tree -> srow[b, l]
-//   reduce: thread (b, w) adds s_l for l = w, w + 4, ... in ascending order; out[b] = ((p0 + p1) + (p2 + p3)) / L
+//   reduce: one wave per image, lane i adds s_l for l = i, i + 64, ... in ascending order, xor-shuffle tree; out[b] = sum / L
 __global__ void __launch_bounds__(256) ee_probe_rows_kernel(const float* __restrict__ x, const float* __restrict__ w_base,
                                                             const float* __restrict__ bias_base, float* __restrict__ srow, int L,
                                                             int D, const StepState* __restrict__ st, int t_mul, int add) {
@@ -790,14 +821,17 @@ __global__ void __launch_bounds__(256) ee_probe_rows_kernel(const float* __restr
         }
     }
 }
+// One wave per (image, layer) row of L sigmoids: lane i adds s_l for l = i, i + 64, ... in ascending order (coalesced 256-byte reads), then the
+// xor-shuffle tree; out = sum / L.  (Four threads per row walked it with 4-byte strided reads: 36 us for the 13 x 64 rows of one early-exit step
+// on 13 workgroups, on every step's critical path.)
 __global__ void __launch_bounds__(256) ee_probe_reduce_kernel(const float* __restrict__ srow, float* __restrict__ out, int B, int L) {
-    const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 2, w = t & 3;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
     float acc = 0.f;
-    if (b < B)
-        for (int l = w; l < L; l += 4) acc += srow[(long long)b * L + l];
-    const int base = (threadIdx.x & 63) & ~3;
-    const float p0 = __shfl(acc, base), p1 = __shfl(acc, base + 1), p2 = __shfl(acc, base + 2), p3 = __shfl(acc, base + 3);
-    if (b < B && w == 0) out[b] = ((p0 + p1) + (p2 + p3)) / (float)L;
+    for (int l = lane; l < L; l += 64) acc += srow[(long long)b * L + l];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[b] = acc / (float)L;
 }
 
 // AttentionProbe (early_exit.py:40-80): one learned query attends over the tokens after the first, then Linear -> SiLU ->
@@ -1292,12 +1326,12 @@ hipError_t launch_affine_step(const float* x, const float* m, const float* z, fl
 hipError_t launch_ee_probe(const float* x, const float* w_base, const float* bias_base, float* out, float* srow, int B, int L, int D,
                            const StepState* st, int t_mul, int add, hipStream_t s) {
     hipLaunchKernelGGL(ee_probe_rows_kernel, dim3(B, 8), dim3(256), 0, s, x, w_base, bias_base, srow, L, D, st, t_mul, add);
-    if (out) hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, srow, out, B, L);     // (out == null: launch_ee_probe_reduce later, for several layers at once)
+    if (out) hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((B + 3) / 4), dim3(256), 0, s, srow, out, B, L);     // (out == null: launch_ee_probe_reduce later, for several layers at once)
     return hipGetLastError();
 }
 // the reduce half alone, for `rows` (image, layer) rows of L sigmoids each: srow [rows, L] -> out [rows], the per-row arithmetic of launch_ee_probe
 hipError_t launch_ee_probe_reduce(const float* srow, float* out, int rows, int L, hipStream_t s) {
-    hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((4 * rows + 255) / 256), dim3(256), 0, s, srow, out, rows, L);
+    hipLaunchKernelGGL(ee_probe_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, srow, out, rows, L);
     return hipGetLastError();
 }
 hipError_t launch_ee_attn_probe(const float* x, const AttnProbeW& w, float* out, int B, int L, int D, hipStream_t s) {
@@ -1310,6 +1344,15 @@ hipError_t launch_ee_select(const float* outs, const float* eps, const float* cl
     hipLaunchKernelGGL(ee_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, outs, eps, cls, thr, depth, B, chw, mo, idx, st,
                        idx_stride > 0 ? idx_stride : B, idx_col0);
     if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B, st, sums ? 1.0f : 0.0f);
+    return hipGetLastError();
+}
+hipError_t launch_ee_select_step(float* x, const float* outs, const float* eps, const float* cls, float thr, int depth, int* idx, float* err_mean,
+                                 int idx_stride, int idx_col0, bool sums, StepState* st, const StepCoef* coef, int B, int C, int S,
+                                 int noise_mode, int advance, hipStream_t s) {
+    const long long npix = (long long)B * S * S;
+    if (err_mean) hipLaunchKernelGGL(ee_batch_mean_kernel, dim3(depth), dim3(64), 0, s, cls, err_mean, B, st, sums ? 1.0f : 0.0f);
+    hipLaunchKernelGGL(ee_select_step_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, outs, eps, cls, thr, depth, idx,
+                       idx_stride > 0 ? idx_stride : B, idx_col0, st, coef, B, C, S, noise_mode, advance, (long long)idx_col0 * S * S);
     return hipGetLastError();
 }
 hipError_t launch_ee_mean_combine(const float* s0, const float* s1, float* err, int depth, int t_lo, int t_hi, int B, hipStream_t s) {

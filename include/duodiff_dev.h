@@ -39,6 +39,15 @@ int dd_dev_mlp(dd_ctx* ctx, int M, int D, int hidden, int extras, const float* h
 int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const float* h_host, const float* wqkv, const float* bqkv,
                          unsigned short* out_host, int iters, void* stream, float* ms_out);
 
+/* Development harness for the output head's first launch (rowops.hip head_dec_kernel; reference models/uvit.py:377-378):
+ * dec = decoder_pred(LayerNorm(x)) in exact fp32 from host arrays x [M, D], norm gamma / beta [D], decoder_pred weight [pd, D] / bias [pd];
+ * dec_host [M, pd] (rows the launch does not decode -- the first tok_e rows of every tok_l-row image when tok_l > 0 -- come back as NaN).
+ * probe_w [D] + probe_b [1] + srow_host [M] or NULL (D = 256 / 512): the early-exit MLP probe's per-row value sigmoid(x . w + b) from the
+ * same launch, for EVERY row (reference models/early_exit.py:31-37).  `iters` timed launches -> ms_out. */
+int dd_dev_head_dec(dd_ctx* ctx, int M, int D, int pd, int tok_l, int tok_e, const float* x_host, const float* norm_g, const float* norm_b,
+                    const float* wdec, const float* bdec, float* dec_host, const float* probe_w, const float* probe_b, float* srow_host,
+                    int iters, void* stream, float* ms_out);
+
 /* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
  * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
  * reads no environment variable. */
