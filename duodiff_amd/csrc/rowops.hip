@@ -1298,8 +1298,8 @@ hipError_t launch_final(const FinalArgs& a, hipStream_t s) {
     if (a.S >= 16) {
         const int tiles = (a.S + 15) / 16;
         const dim3 grid(a.B * tiles * tiles);
-        if (a.C == 3 && a.P == 4) hipLaunchKernelGGL((final_tiled_kernel<3, 4>), grid, dim3(256), 0, s, a);          // CelebA-64, CIFAR-10
-        else if (a.C == 3 && a.P == 2) hipLaunchKernelGGL((final_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a);     // ImageNet-64
+        if (a.C == 3 && a.P == 4) hipLaunchKernelGGL((final_tiled_kernel<3, 4>), grid, dim3(256), 0, s, a);          // CelebA-64, ImageNet-64
+        else if (a.C == 3 && a.P == 2) hipLaunchKernelGGL((final_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a);     // CIFAR-10
         else if (a.C == 4 && a.P == 2) hipLaunchKernelGGL((final_tiled_kernel<4, 2>), grid, dim3(256), 0, s, a);     // latent 32 x 32 x 4
         else hipLaunchKernelGGL((final_tiled_kernel<0, 0>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
