@@ -208,3 +208,19 @@ def test_documents_quote_the_committed_profiles():
     import sys
     r = subprocess.run([sys.executable, str(REPO / "tools" / "perf_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_hand_counted_loads_of_the_output_head_are_never_touched_in_flight():
+    """head_dec_kernel (embed_dim <= 512) issues its row quads and its share of the decoder weights as asm loads hipcc does not count and waits
+    for them with hand-written s_waitcnt vmcnt(N).  tools/isa_audit_head.py compiles rowops.hip for gfx950 and proves on the ISA -- a forward
+    dataflow over every instantiation's basic blocks -- that no instruction names a destination register between its load and the wait that
+    covers it (a phi copy did, once: every early-exit probe value was wrong), that there are no spills or AGPR parks, and that the MFMAs start
+    before the last wait.  Cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "isa_audit_head.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": OK") >= 11
