@@ -17,6 +17,7 @@ DD_DEV_NO_FUSED_MLP, DD_DEV_NO_FUSED_PROJ, DD_DEV_NO_FUSED_HEAD, DD_DEV_GENERIC_
 DD_DEV_NO_FUSED_SKIP, DD_DEV_NO_FUSED_QKV, DD_DEV_NO_FUSED_QA = 32, 64, 128
 DD_PROF_DOMINANT, DD_PROF_BLOCK_TAIL, DD_PROF_FC1, DD_PROF_ROWLIN, DD_PROF_QKV_ATTENTION, DD_PROF_SPLITK = 0, 1, 2, 3, 4, 5
 DD_DEV_NO_CHAINS, DD_DEV_FORCE_CHAINS, DD_DEV_NO_ROWLIN, DD_DEV_NO_ROWLIN_PROJ, DD_DEV_NO_EMBED_LN, DD_DEV_NO_SPLITK, DD_DEV_NO_ROWLIN_SKIP = 256, 512, 1024, 2048, 4096, 8192, 16384
+DD_DEV_NO_SPLIT_HEADS = 32768
 
 
 class dd_config(C.Structure):
@@ -92,7 +93,7 @@ SIGNATURES = {
     "dd_dev_qkv_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_mlp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)] + [C.c_void_p] * 8),
-    "dd_dev_head_dec": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "dd_dev_head_dec": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "dd_dev_poison_workspaces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dd_dev_graph_captures": (C.c_longlong, [C.c_void_p]),
     "dd_dev_last_sample_chains": (C.c_int, [C.c_void_p]),

@@ -94,7 +94,7 @@ static void fold_head_norm(int D, int pd, const float* wd, const float* bd, cons
     }
 }
 
-struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred; dc = c [pd], row sums of wg [pd]) or null
+struct HeadW { const float *ng, *nb, *wdec, *bdec, *wconv, *bconv; const float *wg = nullptr, *dc = nullptr; const float *wsplit = nullptr, *dcs = nullptr; };   // wg / dc: head_dec_kernel operands (norm folded into decoder_pred; dc = c [pd], row sums of wg [pd]) or null; wsplit / dcs: the same for the split-bf16 product (bf16 engine, embed_dim 256 / 512) or null
 
 struct GraphKey {
     const void* x; const void* y; int B, noise, variance, num_cus;   // num_cus: the captured persistent grids are sized from it
@@ -560,6 +560,7 @@ int run_backbone(dd_model* m, const float* x_img, const float* t_vec, const int6
             bool probe_done = false;
             if (hd.wg) {   // the head's LayerNorm + decoder_pred in one exact-fp32 launch (the final head's kernel), patch rows only
                 HeadDecArgs ha{xin, hd.wg, hd.dc, ee_dec_all ? ee_dec_all + (size_t)bi * M * m->pd : m->dec, M, m->pd, (L - m->extras) % 16 == 0 ? L : 0, m->extras};
+                if (hd.wsplit) { ha.wg = hd.wsplit; ha.c = hd.dcs; ha.split = 1; }      // (bf16 engine: the split-bf16 product, rowops.hip SPLIT)
                 if (ee_srow_all && m->ee_type != DD_EE_ATTENTION_PROBE && head_dec_probe_supported(D)) {   // ... and the MLP probe's per-token values of the same rows
                     ha.srow = ee_srow_all + (size_t)bi * B * L; ha.pw_base = m->probe_w; ha.pb_base = m->probe_b; ha.st = c->st; ha.t_mul = t_mul; ha.add = add;
                     probe_done = true;
@@ -1245,7 +1246,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     const size_t o_wdec = put_f32(P("decoder_pred.weight").data(), (size_t)m->pd * D), o_bd = put_f32(P("decoder_pred.bias").data(), m->pd);
     const size_t o_wc = put_f32(P("final_layer.weight").data(), P("final_layer.weight").size());
     const size_t o_bc = put_f32(P("final_layer.bias").data(), m->cfg.in_chans);
-    struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv, wg, dc; };
+    struct HeadOff { size_t ng, nb, wdec, bdec, wconv, bconv, wg, dc, ws, dcs; };
+    const bool split_heads = fused_head && es == 2 && head_dec_probe_supported(D) && !(c->dev_flags & DD_DEV_NO_SPLIT_HEADS);
     struct AttnProbeOff { size_t u, wvt, bv, w0t, b0, w2, b2; };
     std::vector<AttnProbeOff> aoffs;
     std::vector<HeadOff> hoffs;
@@ -1263,6 +1265,13 @@ int dd_model_finalize(dd_model* m, int precision) {
                 std::vector<float> wg, dc;
                 fold_head_norm(D, m->pd, wd.data(), bd.data(), ng.data(), nbv.data(), wg, dc);
                 o.wg = put_f32(wg.data(), wg.size()); o.dc = put_f32(dc.data(), dc.size());
+                if (split_heads) {      // the early-exit heads of the bf16 engine: Wg as hi + lo bf16 halves in the SPLIT kernel's fragment order
+                    const int nt = (m->pd + 15) / 16;
+                    std::vector<unsigned short> img((size_t)(D / 32) * nt * 2 * 64 * 8);
+                    std::vector<float> dcs(dc);
+                    pack_head_split(D, m->pd, wg.data(), host_f2bf, img.data(), dcs.data() + m->pd);
+                    o.ws = put_f32(reinterpret_cast<const float*>(img.data()), img.size() / 2); o.dcs = put_f32(dcs.data(), dcs.size());
+                }
             }
             hoffs.push_back(o);
         }
@@ -1324,7 +1333,8 @@ int dd_model_finalize(dd_model* m, int precision) {
     }
     if (m->cfg.mlp_time_embed) { m->tm_w1t = F(o_tm[0]); m->tm_b1 = F(o_tm[1]); m->tm_w2t = F(o_tm[2]); m->tm_b2 = F(o_tm[3]); }
     m->emb_wt = F(o_wt); m->emb_b = F(o_eb); m->pos = F(o_pos); m->label = m->cfg.num_classes > 0 ? F(o_lab) : nullptr;
-    for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv), fused_head ? F(o.wg) : nullptr, fused_head ? F(o.dc) : nullptr});
+    for (const HeadOff& o : hoffs) m->heads.push_back(HeadW{F(o.ng), F(o.nb), F(o.wdec), F(o.bdec), F(o.wconv), F(o.bconv), fused_head ? F(o.wg) : nullptr, fused_head ? F(o.dc) : nullptr,
+                                                            split_heads ? F(o.ws) : nullptr, split_heads ? F(o.dcs) : nullptr});
     if (m->heads.size() >= 2) {
         m->ee_wconv_stride = m->heads[1].wconv - m->heads[0].wconv; m->ee_bconv_stride = m->heads[1].bconv - m->heads[0].bconv;
         m->ee_conv_stride_ok = true;
@@ -2068,14 +2078,22 @@ int dd_dev_qkv_attention(dd_ctx* c, int B, int L, int H, int extras, const float
 
 int dd_dev_head_dec(dd_ctx* c, int M, int D, int pd, int tok_l, int tok_e, const float* x_host, const float* norm_g, const float* norm_b,
                     const float* wdec, const float* bdec, float* dec_host, const float* probe_w, const float* probe_b, float* srow_host,
-                    int iters, void* stream, float* ms_out) {
+                    int split, int iters, void* stream, float* ms_out) {
     if (!c || !x_host || !norm_g || !norm_b || !wdec || !bdec || !dec_host || M < 1 || iters < 0) return DD_ERR_INVALID;
     if (!head_dec_supported(D, pd)) return fail(c, DD_ERR_UNSUPPORTED, "head_dec: D in {256, 512, 768, 1024}, pd % 4 == 0, pd <= 64");
     const bool probe = probe_w && probe_b && srow_host;
     if (probe && !head_dec_probe_supported(D)) return fail(c, DD_ERR_UNSUPPORTED, "head_dec with the probe: D in {256, 512}");
     hipStream_t s = (hipStream_t)stream;
+    if (split && !head_dec_probe_supported(D)) return fail(c, DD_ERR_UNSUPPORTED, "head_dec as a split-bf16 product: D in {256, 512}");
     std::vector<float> wg, dc;
     fold_head_norm(D, pd, wdec, bdec, norm_g, norm_b, wg, dc);
+    if (split) {      // wg becomes the packed image (as floats: two bf16 each), dc's second half the row sums of hi + lo
+        const int nt = (pd + 15) / 16;
+        std::vector<unsigned short> img((size_t)(D / 32) * nt * 2 * 64 * 8);
+        pack_head_split(D, pd, wg.data(), host_f2bf, img.data(), dc.data() + pd);
+        wg.assign(img.size() / 2, 0.f);
+        std::memcpy(wg.data(), img.data(), img.size() * 2);
+    }
     void *dX = nullptr, *dW = nullptr, *dC = nullptr, *dO = nullptr, *dP = nullptr, *dPb = nullptr, *dS = nullptr;
     auto cleanup = [&]() { for (void* p : {dX, dW, dC, dO, dP, dPb, dS}) if (p) (void)hipFree(p); };
 #define DD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(c, DD_ERR_HIP, hipGetErrorString(e_)); } } while (0)
@@ -2085,6 +2103,7 @@ int dd_dev_head_dec(dd_ctx* c, int M, int D, int pd, int tok_l, int tok_e, const
     DD_TRY(hipMemcpy(dC, dc.data(), dc.size() * 4, hipMemcpyHostToDevice));
     DD_TRY(hipMemset(dO, 0xFF, (size_t)M * pd * 4));      // NaN: rows the launch does not decode stay recognisable
     HeadDecArgs ha{(const float*)dX, (const float*)dW, (const float*)dC, (float*)dO, M, pd, tok_l, tok_e};
+    ha.split = split ? 1 : 0;
     if (probe) {
         DD_TRY(hipMalloc(&dP, (size_t)D * 4)); DD_TRY(hipMalloc(&dPb, 4)); DD_TRY(hipMalloc(&dS, (size_t)M * 4));
         DD_TRY(hipMemcpy(dP, probe_w, (size_t)D * 4, hipMemcpyHostToDevice));

@@ -289,8 +289,12 @@ struct HeadDecArgs {
     const float* pb_base = nullptr;
     const StepState* st = nullptr;
     int t_mul = 0, add = 0;
+    int split = 0;     // 1: wg is the packed split-bf16 image (pack_head_split) and c's row sums are of hi + lo; D = 256 / 512 (rowops.hip: SPLIT)
 };
 bool head_dec_probe_supported(int D);
+// Wg [pd, D] -> the SPLIT kernel's image: [jj < D / 32][ct < nt][hi, lo][64 lanes] x 8 bf16 (2 D nt 16 bf16 = the fp32 matrix's bytes at pd = 16 nt);
+// wsum [pd]: the row sums of hi + lo (what the kernel multiplies)
+void pack_head_split(int D, int pd, const float* wg, unsigned short (*f2bf)(float), unsigned short* img, float* wsum);
 bool head_dec_supported(int D, int pd);
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s);
 

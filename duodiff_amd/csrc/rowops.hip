@@ -3,7 +3,9 @@
 // All arithmetic here is fp32 in both precision modes.
 #include "dd_internal.h"
 
+#include <cstring>
 #include <utility>
+#include <vector>
 
 #include <cstdlib>
 
@@ -1041,9 +1043,25 @@ __device__ __forceinline__ void landed_at_vmcnt(f32x4& v) {
 //     srow[row] = sigmoid(x[row,:] . w + b)        (w, b: probe row t * t_mul + add, t read from the step state as in ee_probe_rows_kernel)
 // for the rows it decodes -- the quads are in registers anyway: 4 VALU fmas per quad under the MFMAs instead of a second pass over the
 // rows in HBM (13 launches per step) -- and, patch-rows-only launches, for the extra-token rows in a short pass of their own behind the units.
-template <int D, int NT, int NW = 8, bool PROBE = false>
+// SPLIT (the early-exit heads of the bf16 engine; the model's final head and the fp32 engine keep the exact product): Wg . d as a split-bf16
+// product on v_mfma_f32_16x16x32_bf16 -- Wg = Wh + Wl and d = dh + dl, each half a bf16 (the low half = the bf16 of the remainder), and
+// Wh.dh + Wh.dl + Wl.dh accumulated in fp32; the dropped Wl.dl term and the low halves' own rounding are 2^-16 .. 2^-17 of a product, two
+// orders below the bf16 roundings of the backbone that feeds these heads -- 9 MFMAs of 16 cycles per 32 k instead of 24 of 32 cycles (a fifth
+// of the matrix-pipe time, and of its energy).  Lane (row l & 15, k-group l >> 4) holds k = 32 jj + 8 (l >> 4) .. + 7 as TWO quads per jj;
+// a.wg is the host-packed image [jj][ct][hi, lo][64 lanes] x 8 bf16 in A-operand order (capi.hip: pack_head_split).
+__device__ __forceinline__ unsigned head_pack2_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+    typedef float f32v2 __attribute__((ext_vector_type(2)));
+    const f32v2 q = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16v2));
+}
+
+template <int D, int NT, int NW = 8, bool PROBE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) {
     constexpr int J = D / 16;
+    // quad jq of a lane: byte offset from the lane's base (row, k-group) and its index in the probe row's quads
+    constexpr auto quad_off = [](int jq) constexpr { return SPLIT ? 128 * (jq / 2) + 16 * (jq % 2) : 64 * jq; };
+    constexpr int KG = SPLIT ? 8 : 4;      // floats between the k-groups' bases
     constexpr bool HAND = J + J * NT / NW + (PROBE ? 1 : 0) <= 52;     // D <= 512: J row quads + the Wg share <= 63 operations in flight, all of them in VGPRs (<= 208 of 256)
     extern __shared__ __attribute__((aligned(16))) char head_lds[];
     f32x4* wl = reinterpret_cast<f32x4*>(head_lds);                 // [J][NT][64]
@@ -1070,16 +1088,17 @@ __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) 
     f32x4 xv[J];
     auto request = [&](int u) {     // this lane's quads of its row of unit u (rows past M: the last row, never stored)
         const long long row = row_of(u);
-        const float* xr = a.x + (row < a.M ? row : (long long)a.M - 1) * D + 4 * q;
+        const float* xr = a.x + (row < a.M ? row : (long long)a.M - 1) * D + KG * q;
         [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
-            (asm_load_quad<64 * JJ, HAND>(xv[JJ], xr), ...);
+            (asm_load_quad<quad_off(JJ), HAND>(xv[JJ], xr), ...);
         }(std::make_integer_sequence<int, J>{});
     };
     // Wg fragments of this wave (L2-resident) -> LDS in A-operand order; requested FIRST, the first unit's rows right behind
     // them: the rows are in flight while the workgroup parks Wg and meets at the barrier
     constexpr int WI = J * NT / NW;
     static_assert(J * NT % NW == 0, "one equal share of Wg fragments per wave");
-    static_assert(64 * (J - 1) < 4096, "the row quads' immediate offsets");
+    static_assert(quad_off(J - 1) < 4096, "the row quads' immediate offsets");
+    static_assert(!SPLIT || (HAND && J % 2 == 0), "the split product is built for the hand-counted widths");
     static_assert(!HAND || J + WI <= 63, "the vector-memory counter holds 63 operations");
     int u = wave * (int)gridDim.x + (int)blockIdx.x;
     {
@@ -1087,7 +1106,8 @@ __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) 
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int item = wave + NW * i, j = item / NT, ct = item - j * NT, m = 16 * ct + n;
-            const float* wp = a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q;   // (rows m >= pd feed output columns that are never stored)
+            const float* wp = SPLIT ? a.wg + (long long)item * 256 + lane * 4      // (the packed image: item = (jj NT + ct) 2 + half, 1 KB each)
+                                    : a.wg + (long long)(m < a.pd ? m : 0) * D + 16 * j + 4 * q;   // (rows m >= pd feed output columns that are never stored)
             asm_load_quad<0, HAND>(wv[i], wp);
         }
         // (every wave requests a quad of the probe row, D / 256 of them park theirs: an asm load under a branch hands hipcc a phi
@@ -1119,7 +1139,7 @@ __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) 
         f32x4 acc[NT];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        lds_quad_ptr pwp = (lds_quad_ptr)pwl + q;
+        lds_quad_ptr pwp = (lds_quad_ptr)pwl + (SPLIT ? 2 * q : q);
         asm volatile("" : "+v"(pwp));
         f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
         [&]<int... JJ>(std::integer_sequence<int, JJ...>) {      // fully unrolled: xv[] must stay in registers
@@ -1127,19 +1147,40 @@ __global__ void __launch_bounds__(NW * 64) head_dec_kernel(const HeadDecArgs a) 
                 constexpr int j = JJ;
                 landed_at_vmcnt<J - 1 - j, HAND>(xv[j]);      // quad j has landed
                 if constexpr (PROBE) {
-                    const f32x4 pw4 = pwp[4 * j];
+                    const f32x4 pw4 = pwp[SPLIT ? 8 * (j / 2) + (j % 2) : 4 * j];      // (pwp = the probe row's quads + q (2 q with SPLIT))
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pacc[e] = fmaf(xv[j][e], pw4[e], pacc[e]);
                     asm volatile("" : "+v"(pacc));      // (here, not after the loop: hipcc parked every quad and probe weight in scratch to run the 128 fmas at the end)
                 }
                 xv[j] = xv[j] - x0;
-                f32x4 w[NT];
+                if constexpr (!SPLIT) {
+                    f32x4 w[NT];
 #pragma unroll
-                for (int ct = 0; ct < NT; ++ct) w[ct] = wlp[(j * NT + ct) * 64];
+                    for (int ct = 0; ct < NT; ++ct) w[ct] = wlp[(j * NT + ct) * 64];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][e], xv[j][e], acc[ct], 0, 0, 0);
+                        for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][e], xv[j][e], acc[ct], 0, 0, 0);
+                } else if constexpr (j % 2 == 1) {      // both quads of k-block jj = j / 2 are here: split, then 3 NT MFMAs
+                    constexpr int jj = j / 2;
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 hi, lo;
+#pragma unroll
+                    for (int p2 = 0; p2 < 4; ++p2) {
+                        const float d0 = p2 < 2 ? xv[j - 1][2 * p2] : xv[j][2 * p2 - 4], d1 = p2 < 2 ? xv[j - 1][2 * p2 + 1] : xv[j][2 * p2 - 3];
+                        const unsigned h = head_pack2_bf16(d0, d1);
+                        hi[p2] = h;
+                        lo[p2] = head_pack2_bf16(d0 - __builtin_bit_cast(float, h << 16), d1 - __builtin_bit_cast(float, h & 0xffff0000u));
+                    }
+                    const bf16x8 dh = __builtin_bit_cast(bf16x8, hi), dl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wlp[((jj * NT + ct) * 2) * 64]), wlo = __builtin_bit_cast(bf16x8, wlp[((jj * NT + ct) * 2 + 1) * 64]);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dh, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dl, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, dh, acc[ct], 0, 0, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);     // (hipcc would sink this block's MFMAs below the later waits)
             }(), ...);
         }(std::make_integer_sequence<int, J>{});
@@ -1226,17 +1267,40 @@ bool head_dec_supported(int D, int pd) {
 
 bool head_dec_probe_supported(int D) { return D == 256 || D == 512; }
 
+void pack_head_split(int D, int pd, const float* wg, unsigned short (*f2bf)(float), unsigned short* img, float* wsum) {
+    const int nt = (pd + 15) / 16, J2 = D / 32;
+    auto bf2f = [](unsigned short b) { const unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    std::vector<double> sums(pd, 0.0);
+    for (int jj = 0; jj < J2; ++jj)
+        for (int ct = 0; ct < nt; ++ct)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = 16 * ct + (lane & 15), k0 = 32 * jj + 8 * (lane >> 4);
+                unsigned short* hi = img + ((size_t)((jj * nt + ct) * 2) * 64 + lane) * 8;
+                unsigned short* lo = hi + 64 * 8;
+                for (int e = 0; e < 8; ++e) {
+                    const float w = m < pd ? wg[(size_t)m * D + k0 + e] : 0.f;       // (rows m >= pd feed output columns that are never stored)
+                    hi[e] = f2bf(w);
+                    lo[e] = f2bf(w - bf2f(hi[e]));
+                    if (m < pd) sums[m] += (double)bf2f(hi[e]) + (double)bf2f(lo[e]);
+                }
+            }
+    for (int m = 0; m < pd; ++m) wsum[m] = (float)sums[m];
+}
+
 hipError_t launch_head_dec(const HeadDecArgs& a, int D, int num_cus, hipStream_t s) {
     if (!head_dec_supported(D, a.pd) || a.M < 1) return hipErrorInvalidValue;
     if (a.tok_l > 0 && (a.tok_e < 0 || a.tok_e >= a.tok_l || (a.tok_l - a.tok_e) % 16 || a.M % a.tok_l)) return hipErrorInvalidValue;
     if (a.srow && (!head_dec_probe_supported(D) || !a.pw_base || !a.pb_base || (a.t_mul && !a.st))) return hipErrorInvalidValue;
+    if (a.split && !head_dec_probe_supported(D)) return hipErrorInvalidValue;     // (the same widths: 256 / 512)
     const int nt = (a.pd + 15) / 16;
     const int wgs = (a.M + 127) / 128;
     const dim3 grid((unsigned)(wgs < num_cus ? wgs : num_cus));     // one workgroup per CU (LDS), 16-row units dealt inside
     const size_t lds = (size_t)(D / 16) * nt * 1024 + (a.srow ? (size_t)D * 4 : 0);
 #define DD_HEAD(DV, NV)                                                                                  \
     do {                                                                                                 \
-        if (a.srow) hipLaunchKernelGGL((head_dec_kernel<DV, NV, 8, true>), grid, dim3(512), lds, s, a);  \
+        if (a.split && a.srow) hipLaunchKernelGGL((head_dec_kernel<DV, NV, 8, true, true>), grid, dim3(512), lds, s, a);   \
+        else if (a.split) hipLaunchKernelGGL((head_dec_kernel<DV, NV, 8, false, true>), grid, dim3(512), lds, s, a);       \
+        else if (a.srow) hipLaunchKernelGGL((head_dec_kernel<DV, NV, 8, true>), grid, dim3(512), lds, s, a);  \
         else hipLaunchKernelGGL((head_dec_kernel<DV, NV>), grid, dim3(512), lds, s, a);                  \
     } while (0)
     if (D == 1024) {
@@ -1259,7 +1323,11 @@ hipError_t init_rowops_kernels() {
     if (e == hipSuccess)                                                                                           \
         e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024); \
     if (e == hipSuccess)                                                                                           \
-        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024 + DV * 4);
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024 + DV * 4); \
+    if (e == hipSuccess)                                                                                           \
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024 + DV * 4); \
+    if (e == hipSuccess)                                                                                           \
+        e = hipFuncSetAttribute((const void*)head_dec_kernel<DV, NV, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DV / 16) * NV * 1024);
     DD_HEAD_ATTR(512, 1) DD_HEAD_ATTR(512, 2) DD_HEAD_ATTR(512, 3) DD_HEAD_ATTR(512, 4)
     DD_HEAD_ATTR(256, 1) DD_HEAD_ATTR(256, 2) DD_HEAD_ATTR(256, 3) DD_HEAD_ATTR(256, 4)
 #undef DD_HEAD_ATTR

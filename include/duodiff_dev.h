@@ -43,10 +43,11 @@ int dd_dev_qkv_attention(dd_ctx* ctx, int B, int L, int H, int extras, const flo
  * dec = decoder_pred(LayerNorm(x)) in exact fp32 from host arrays x [M, D], norm gamma / beta [D], decoder_pred weight [pd, D] / bias [pd];
  * dec_host [M, pd] (rows the launch does not decode -- the first tok_e rows of every tok_l-row image when tok_l > 0 -- come back as NaN).
  * probe_w [D] + probe_b [1] + srow_host [M] or NULL (D = 256 / 512): the early-exit MLP probe's per-row value sigmoid(x . w + b) from the
- * same launch, for EVERY row (reference models/early_exit.py:31-37).  `iters` timed launches -> ms_out. */
+ * same launch, for EVERY row (reference models/early_exit.py:31-37).  split != 0 (D = 256 / 512): the product as a split-bf16 product (hi + lo halves,
+ * three bf16 MFMAs: 2^-16 of a product; what the bf16 engine's early-exit heads run) instead of the exact fp32 one.  `iters` timed launches -> ms_out. */
 int dd_dev_head_dec(dd_ctx* ctx, int M, int D, int pd, int tok_l, int tok_e, const float* x_host, const float* norm_g, const float* norm_b,
                     const float* wdec, const float* bdec, float* dec_host, const float* probe_w, const float* probe_b, float* srow_host,
-                    int iters, void* stream, float* ms_out);
+                    int split, int iters, void* stream, float* ms_out);
 
 /* Kernel-variant switches for same-process A/B runs (tools/mlp_check.py, tools/all_configs.py).  They act on models
  * FINALIZED after the call (the first three) or on launches made after it; the product never sets them and the library
@@ -65,6 +66,7 @@ int dd_dev_head_dec(dd_ctx* ctx, int M, int D, int pd, int tok_l, int tok_e, con
 #define DD_DEV_NO_EMBED_LN 4096u     /* keep the first block's norm1 as its own launch (default: written by the patch-embed launch where it fits) */
 #define DD_DEV_NO_SPLITK 8192u       /* small-batch GEMM-path models: keep skip_linear / attn.proj / mlp.fc2 as whole-K GEMMs + LayerNorm launches */
 #define DD_DEV_NO_ROWLIN_SKIP 16384u /* embed_dim 768: keep the out-blocks' skip_linear as a GEMM + LayerNorm launch pair */
+#define DD_DEV_NO_SPLIT_HEADS 32768u /* early-exit heads of the bf16 engine: keep the exact-fp32 decoder product (default: the split-bf16 product at embed_dim 256 / 512) */
 #define DD_DEV_FORCE_CHAINS 512u    /* dd_sample: two half-batch chains for ANY even batch (tests at small batches) */
 int dd_dev_set_flags(dd_ctx* ctx, unsigned flags);
 

@@ -25,7 +25,7 @@ def _reference(x, g, b, w, bias):
     return xn @ w.astype(np.float64).T + bias.astype(np.float64)
 
 
-def _run(M, D, pd, tok_l, tok_e, x, probe):
+def _run(M, D, pd, tok_l, tok_e, x, probe, split=0):
     from duodiff_amd.engine import Context
     ctx = Context.get()
     r = np.random.default_rng(D + pd)
@@ -40,7 +40,7 @@ def _run(M, D, pd, tok_l, tok_e, x, probe):
     ms = C.c_float(0)
     P = lambda a: a.ctypes.data
     ctx.check(ctx.lib.dd_dev_head_dec(ctx.handle, M, D, pd, tok_l, tok_e, P(x), P(g), P(b), P(w), P(bias), P(dec),
-                                      P(pw) if probe else None, P(pb) if probe else None, P(srow) if probe else None, 3, None, C.byref(ms)))
+                                      P(pw) if probe else None, P(pb) if probe else None, P(srow) if probe else None, split, 3, None, C.byref(ms)))
     want = _reference(x, g, b, w, bias)
     with np.errstate(over="ignore"):
         want_s = 1.0 / (1.0 + np.exp(-(x.astype(np.float64) @ pw.astype(np.float64) + 0.3)))
@@ -87,3 +87,28 @@ def test_head_dec_every_row_ragged_and_more_units_than_waves(D, pd, M, probe):
     assert err.max() <= 5e-6 * max(1.0, np.abs(want).max())
     if probe:
         assert np.abs(srow - want_s).max() <= 2e-6
+
+
+@pytest.mark.parametrize("D,pd,B,L,extras,probe", [(512, 48, 5, 257, 1, True), (512, 48, 3, 258, 2, False), (256, 48, 3, 65, 1, True), (512, 64, 2, 257, 1, True),
+                                                   (512, 12, 3, 258, 2, True), (256, 16, 4, 17, 1, False), (512, 48, 64, 257, 1, True)])
+def test_head_dec_split_bf16_product_against_float64_reference(D, pd, B, L, extras, probe):
+    """The early-exit heads of the bf16 engine: Wg . d as hi + lo bf16 halves and three bf16 MFMAs.  The dropped lo . lo term and the low
+    halves' rounding are 2^-16 .. 2^-17 of a product: a few 1e-5 of the output's scale at most (the exact kernel: 2e-6), offset rows included
+    -- the split is of d = x - x[0], not of x; the probe value comes from the fp32 rows as in the exact kernel."""
+    M = B * L
+    r = np.random.default_rng(M + D + 1)
+    x = r.standard_normal((M, D)).astype(np.float32)
+    x[1::4] += 50.0
+    x[2::4] += 2000.0
+    x[3::4] *= 1e-3
+    dec, srow, want, want_s, us = _run(M, D, pd, L, extras, x, probe, split=1)
+    exact, _, _, _, us_exact = _run(M, D, pd, L, extras, x, probe, split=0)
+    patch = (np.arange(M) % L) >= extras
+    assert np.isnan(dec[~patch]).all()
+    err = np.abs(dec[patch] - want[patch])
+    scale = np.abs(want[patch]).max()
+    print(f"head_dec split D={D} pd={pd} B={B} L={L}: max err {err.max():.3e} of |dec| max {scale:.2f} (exact kernel {np.abs(exact[patch] - want[patch]).max():.3e}); "
+          f"{us:.1f} us/launch against {us_exact:.1f} exact")
+    assert err.max() <= 4e-5 * scale
+    if probe:
+        assert np.abs(srow - want_s).max() <= 1e-6

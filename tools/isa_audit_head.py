@@ -22,8 +22,7 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
 SRC = REPO / "duodiff_amd" / "csrc" / "rowops.hip"
-HAND = ["ILi512ELi1ELi8ELb0E", "ILi512ELi2ELi8ELb0E", "ILi512ELi3ELi8ELb0E", "ILi512ELi4ELi8ELb0E", "ILi512ELi3ELi8ELb1E", "ILi512ELi4ELi8ELb1E",
-        "ILi256ELi1ELi8ELb0E", "ILi256ELi3ELi8ELb0E", "ILi256ELi4ELi8ELb0E", "ILi256ELi3ELi8ELb1E", "ILi256ELi1ELi8ELb1E"]
+HAND = [f"ILi{d}ELi{nt}ELi8ELb{pr}ELb{sp}E" for d in (256, 512) for nt in (1, 2, 3, 4) for pr in (0, 1) for sp in (0, 1)]      # <D, NT, 8, PROBE, SPLIT>
 
 
 def regs(tok):
@@ -145,8 +144,8 @@ def main():
         for x in f[:8]:
             print("   ", x)
         rc |= 1 if f else 0
-    if seen < 6:
-        print(f"only {seen} hand-counted instantiations found (expected the D = 256 / 512 ones)")
+    if seen < 32:
+        print(f"only {seen} hand-counted instantiations found (expected 32: D = 256 / 512 x NT 1..4 x PROBE x SPLIT)")
         rc = 1
     return rc
 
