@@ -79,7 +79,7 @@ def main():
     out["early_exit_celeba_b%d" % B] = dict(ms_per_step_early_exit_device_loop=t_ee / K * 1e3, ms_per_step_early_exit_python_loop=t_ee_py / K * 1e3,
                                             ms_per_step_plain_backbone=t_plain / K * 1e3,
                                             overhead_ms_per_step=(t_ee - t_plain) / K * 1e3,
-                                            note=f"{K} steps; early exit = 13 output heads (LayerNorm + fp32 decoder GEMM + unpatchify/conv) + 13 probes + selection on top of the 13-block backbone")
+                                            note=f"{K} steps; early exit = 13 output heads (LayerNorm + decoder product (split-bf16 in the bf16 engine) + unpatchify/conv) + 13 probes (inside the heads' launches) + selection on top of the 13-block backbone")
     print(json.dumps(out), flush=True)
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
